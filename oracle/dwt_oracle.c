@@ -1,0 +1,329 @@
+/*
+ * oracle/dwt_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (float64, single thread) of the arithmetic the reference's
+ * wrapper obtains from PyWavelets (third-party, pinned ==1.5.0 in
+ * /root/reference/requirements.txt:8; 1.1.1 is what exists in this image):
+ *
+ *   encode side  spiht/spiht_wrapper.py:163-172
+ *       pywt.wavedec2 -> pywt.coeffs_to_array -> channel_mults * arr -> quantize
+ *   decode side  spiht/spiht_wrapper.py:259-276
+ *       rec / channel_mults -> dequantize -> pywt.array_to_coeffs -> pywt.waverec2
+ *   geometry     spiht/spiht_wrapper.py:92-139 (pywt.wavedecn_shapes)
+ *
+ * The published definitions restated here:
+ *   analysis   cA[o] = sum_j dec_lo[j] * xe[2o+1-j],  o in [0,(N+F-1)/2)
+ *   synthesis  x[n]  = sum_k cA[k]*rec_lo[n+F-2-2k] + cD[k]*rec_hi[n+F-2-2k],  n in [0,2L-F+2)
+ *   dwt2 filters axis -2 first, then axis -1; idwt2 runs axis -1 first, then -2;
+ *   waverec2 drops the last row/col of the running approximation when it is one
+ *   longer than the next detail band; coeffs_to_array packs bands Mallat-style
+ *   with zero padding.
+ *
+ * Pinning: tests/golden/ holds arrays captured from pywt 1.1.1 through the
+ * reference's own wrapper (tests/golden/make_golden.py); agreement is to <= a
+ * few ulp (pywt sums boundary taps in another order), quantised outputs equal.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXF 20
+
+typedef struct {
+    const char *name;
+    int F;
+    double dec_lo[MAXF], dec_hi[MAXF], rec_lo[MAXF], rec_hi[MAXF];
+} wavelet_t;
+
+/* pywt.Wavelet(name).filter_bank, repr(float) (cross-checked by make_golden.py) */
+static const wavelet_t WAVELETS[] = {
+    {"bior2.2", 6,
+     {0.0, -0.1767766952966369, 0.3535533905932738, 1.0606601717798212, 0.3535533905932738, -0.1767766952966369},
+     {0.0, 0.3535533905932738, -0.7071067811865476, 0.3535533905932738, 0.0, 0.0},
+     {0.0, 0.3535533905932738, 0.7071067811865476, 0.3535533905932738, 0.0, 0.0},
+     {0.0, 0.1767766952966369, 0.3535533905932738, -1.0606601717798212, 0.3535533905932738, 0.1767766952966369}},
+    {"bior4.4", 10,
+     {0.0, 0.03782845550726404, -0.023849465019556843, -0.11062440441843718, 0.37740285561283066,
+      0.8526986790088938, 0.37740285561283066, -0.11062440441843718, -0.023849465019556843, 0.03782845550726404},
+     {0.0, -0.06453888262869706, 0.04068941760916406, 0.41809227322161724, -0.7884856164055829,
+      0.41809227322161724, 0.04068941760916406, -0.06453888262869706, 0.0, 0.0},
+     {0.0, -0.06453888262869706, -0.04068941760916406, 0.41809227322161724, 0.7884856164055829,
+      0.41809227322161724, -0.04068941760916406, -0.06453888262869706, 0.0, 0.0},
+     {0.0, -0.03782845550726404, -0.023849465019556843, 0.11062440441843718, 0.37740285561283066,
+      -0.8526986790088938, 0.37740285561283066, 0.11062440441843718, -0.023849465019556843, -0.03782845550726404}},
+    {"bior6.8", 18,
+     {0.0, 0.0019088317364812906, -0.0019142861290887667, -0.016990639867602342, 0.01193456527972926,
+      0.04973290349094079, -0.07726317316720414, -0.09405920349573646, 0.4207962846098268, 0.8259229974584023,
+      0.4207962846098268, -0.09405920349573646, -0.07726317316720414, 0.04973290349094079, 0.01193456527972926,
+      -0.016990639867602342, -0.0019142861290887667, 0.0019088317364812906},
+     {0.0, 0.0, 0.0, 0.014426282505624435, -0.014467504896790148, -0.07872200106262882, 0.04036797903033992,
+      0.41784910915027457, -0.7589077294536541, 0.41784910915027457, 0.04036797903033992, -0.07872200106262882,
+      -0.014467504896790148, 0.014426282505624435, 0.0, 0.0, 0.0, 0.0},
+     {0.0, 0.0, 0.0, 0.014426282505624435, 0.014467504896790148, -0.07872200106262882, -0.04036797903033992,
+      0.41784910915027457, 0.7589077294536541, 0.41784910915027457, -0.04036797903033992, -0.07872200106262882,
+      0.014467504896790148, 0.014426282505624435, 0.0, 0.0, 0.0, 0.0},
+     {0.0, -0.0019088317364812906, -0.0019142861290887667, 0.016990639867602342, 0.01193456527972926,
+      -0.04973290349094079, -0.07726317316720414, 0.09405920349573646, 0.4207962846098268, -0.8259229974584023,
+      0.4207962846098268, 0.09405920349573646, -0.07726317316720414, -0.04973290349094079, 0.01193456527972926,
+      0.016990639867602342, -0.0019142861290887667, -0.0019088317364812906}},
+    {"haar", 2,
+     {0.7071067811865476, 0.7071067811865476},
+     {-0.7071067811865476, 0.7071067811865476},
+     {0.7071067811865476, 0.7071067811865476},
+     {0.7071067811865476, -0.7071067811865476}},
+};
+#define NWAVELETS ((int)(sizeof(WAVELETS) / sizeof(WAVELETS[0])))
+
+/* modes: 0 reflect, 1 symmetric, 2 periodic, 3 zero, 4 constant */
+enum { MODE_REFLECT = 0, MODE_SYMMETRIC = 1, MODE_PERIODIC = 2, MODE_ZERO = 3, MODE_CONSTANT = 4 };
+
+int orc_wavelet_id(const char *name) {
+    for (int i = 0; i < NWAVELETS; i++)
+        if (!strcmp(WAVELETS[i].name, name)) return i;
+    if (!strcmp(name, "db1")) return orc_wavelet_id("haar");
+    return -1;
+}
+int orc_wavelet_len(int wid) { return (wid >= 0 && wid < NWAVELETS) ? WAVELETS[wid].F : -1; }
+int orc_wavelet_filters(int wid, double *dec_lo, double *dec_hi, double *rec_lo, double *rec_hi) {
+    if (wid < 0 || wid >= NWAVELETS) return -1;
+    const wavelet_t *wv = &WAVELETS[wid];
+    memcpy(dec_lo, wv->dec_lo, sizeof(double) * wv->F);
+    memcpy(dec_hi, wv->dec_hi, sizeof(double) * wv->F);
+    memcpy(rec_lo, wv->rec_lo, sizeof(double) * wv->F);
+    memcpy(rec_hi, wv->rec_hi, sizeof(double) * wv->F);
+    return wv->F;
+}
+
+/* pywt common.c dwt_max_level: floor(log2(len / (F-1))) with integer division */
+int orc_dwt_max_level(int64_t len, int F) {
+    if (F <= 1 || len < F - 1) return 0;
+    int64_t q = len / (F - 1);
+    int l = 0;
+    while (q > 1) { q >>= 1; l++; }
+    return l;
+}
+
+/* wavedec2 level resolution (pywt _multilevel._check_level): None (-1) -> min over the two axes */
+int orc_resolve_level(int64_t H, int64_t W, int F, int level) {
+    if (level >= 0) return level;
+    int a = orc_dwt_max_level(H, F), b = orc_dwt_max_level(W, F);
+    return a < b ? a : b;
+}
+
+/* Geometry (wrapper:92-139 / pywt.wavedecn_shapes): per-level band sizes hs[l], ws[l] for
+ * l = 0..level (0 = image), LL size, and the padded coefficient-array size.  Returns level used. */
+int orc_geometry(int64_t H, int64_t W, int F, int level, int64_t *hs, int64_t *ws, int64_t *ll_h,
+                 int64_t *ll_w, int64_t *enc_h, int64_t *enc_w) {
+    int L = orc_resolve_level(H, W, F, level);
+    hs[0] = H; ws[0] = W;
+    for (int l = 1; l <= L; l++) {
+        hs[l] = (hs[l - 1] + F - 1) / 2;
+        ws[l] = (ws[l - 1] + F - 1) / 2;
+    }
+    *ll_h = hs[L]; *ll_w = ws[L];
+    int64_t ah = hs[L], aw = ws[L];
+    for (int l = L; l >= 1; l--) { ah += hs[l]; aw += ws[l]; }
+    *enc_h = ah; *enc_w = aw;
+    return L;
+}
+
+/* signal extension index map; returns -1 for "zero" */
+static inline int64_t ext_index(int64_t i, int64_t N, int mode) {
+    if (i >= 0 && i < N) return i;
+    switch (mode) {
+    case MODE_REFLECT: {
+        if (N == 1) return 0;
+        int64_t P = 2 * (N - 1);
+        int64_t m = i % P; if (m < 0) m += P;
+        return m < N ? m : P - m;
+    }
+    case MODE_SYMMETRIC: {
+        int64_t P = 2 * N;
+        int64_t m = i % P; if (m < 0) m += P;
+        return m < N ? m : P - 1 - m;
+    }
+    case MODE_PERIODIC: {
+        int64_t m = i % N; if (m < 0) m += N;
+        return m;
+    }
+    case MODE_CONSTANT: return i < 0 ? 0 : N - 1;
+    default: return -1;
+    }
+}
+
+/* 1-D analysis along a strided line */
+static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, const double *hi, int F,
+                     int mode, double *ca, double *cd, int64_t so) {
+    int64_t L = (N + F - 1) / 2;
+    for (int64_t o = 0; o < L; o++) {
+        double a = 0.0, d = 0.0;
+        for (int j = 0; j < F; j++) {
+            int64_t idx = ext_index(2 * o + 1 - j, N, mode);
+            double v = idx < 0 ? 0.0 : x[idx * sx];
+            a += lo[j] * v;
+            d += hi[j] * v;
+        }
+        ca[o * so] = a;
+        cd[o * so] = d;
+    }
+}
+
+/* 1-D synthesis along a strided line; output length 2L-F+2 */
+static void idwt_line(const double *ca, const double *cd, int64_t L, int64_t si, const double *lo,
+                      const double *hi, int F, double *x, int64_t so) {
+    int64_t N = 2 * L - F + 2;
+    for (int64_t n = 0; n < N; n++) {
+        double s = 0.0;
+        for (int64_t k = 0; k < L; k++) {
+            int64_t t = n + F - 2 - 2 * k;
+            if (t < 0 || t >= F) continue;
+            s += ca[k * si] * lo[t] + cd[k * si] * hi[t];
+        }
+        x[n * so] = s;
+    }
+}
+
+/* one 2-D analysis level on one channel: in [h,w] -> aa, ad, da, dd each [h2,w2] (axis -2 first) */
+static int dwt2_level(const double *in, int64_t h, int64_t w, const wavelet_t *wv, int mode, double *aa,
+                      double *ad, double *da, double *dd) {
+    int F = wv->F;
+    int64_t h2 = (h + F - 1) / 2, w2 = (w + F - 1) / 2;
+    double *ta = (double *)malloc(sizeof(double) * h2 * w), *td = (double *)malloc(sizeof(double) * h2 * w);
+    if (!ta || !td) { free(ta); free(td); return -1; }
+    for (int64_t j = 0; j < w; j++) dwt_line(in + j, h, w, wv->dec_lo, wv->dec_hi, F, mode, ta + j, td + j, w);
+    for (int64_t i = 0; i < h2; i++) {
+        dwt_line(ta + i * w, w, 1, wv->dec_lo, wv->dec_hi, F, mode, aa + i * w2, ad + i * w2, 1);
+        dwt_line(td + i * w, w, 1, wv->dec_lo, wv->dec_hi, F, mode, da + i * w2, dd + i * w2, 1);
+    }
+    free(ta); free(td);
+    return 0;
+}
+
+/* wavedec2 + coeffs_to_array (float64 array out, zero padded) : wrapper:163-165 */
+int orc_wavedec2_array(const double *img, int64_t c, int64_t H, int64_t W, int wid, int mode, int level,
+                       double *arr /* [c,enc_h,enc_w] */) {
+    if (wid < 0 || wid >= NWAVELETS) return -1;
+    const wavelet_t *wv = &WAVELETS[wid];
+    int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
+    int L = orc_geometry(H, W, wv->F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    memset(arr, 0, sizeof(double) * c * eh * ew);
+    /* band offsets: level l detail block sits at accumulated offset A_l */
+    int64_t offh[64], offw[64];
+    int64_t ah = ll_h, aw = ll_w;
+    for (int l = L; l >= 1; l--) { offh[l] = ah; offw[l] = aw; ah += hs[l]; aw += ws[l]; }
+    for (int64_t k = 0; k < c; k++) {
+        double *cur = (double *)malloc(sizeof(double) * H * W);
+        if (!cur) return -2;
+        memcpy(cur, img + k * H * W, sizeof(double) * H * W);
+        double *out = arr + k * eh * ew;
+        for (int l = 1; l <= L; l++) {
+            int64_t h2 = hs[l], w2 = ws[l];
+            double *aa = (double *)malloc(sizeof(double) * h2 * w2 * 4);
+            if (!aa) { free(cur); return -2; }
+            double *ad = aa + h2 * w2, *da = ad + h2 * w2, *dd = da + h2 * w2;
+            if (dwt2_level(cur, hs[l - 1], ws[l - 1], wv, mode, aa, ad, da, dd)) { free(aa); free(cur); return -2; }
+            for (int64_t i = 0; i < h2; i++)
+                for (int64_t j = 0; j < w2; j++) {
+                    out[i * ew + offw[l] + j] = ad[i * w2 + j];              /* 'ad': top-right    */
+                    out[(offh[l] + i) * ew + j] = da[i * w2 + j];            /* 'da': bottom-left  */
+                    out[(offh[l] + i) * ew + offw[l] + j] = dd[i * w2 + j];  /* 'dd': bottom-right */
+                }
+            free(cur);
+            cur = (double *)malloc(sizeof(double) * h2 * w2);
+            if (!cur) { free(aa); return -2; }
+            memcpy(cur, aa, sizeof(double) * h2 * w2);
+            free(aa);
+        }
+        for (int64_t i = 0; i < ll_h; i++)
+            for (int64_t j = 0; j < ll_w; j++) out[i * ew + j] = cur[i * ws[L] + j];
+        free(cur);
+    }
+    return 0;
+}
+
+/* wrapper:167-172, :9-11 : int32((m_k * x) * q), truncation toward zero (numpy astype) */
+void orc_quantize(const double *arr, int64_t c, int64_t n_per_c, const double *mults /* or NULL */,
+                  double q, int32_t *out) {
+    for (int64_t k = 0; k < c; k++)
+        for (int64_t t = 0; t < n_per_c; t++) {
+            double v = arr[k * n_per_c + t];
+            if (mults) v = mults[k] * v;
+            v = v * q;
+            out[k * n_per_c + t] = (int32_t)v;
+        }
+}
+
+/* wrapper:270-274, :13-14 : (rec / m_k) / q */
+void orc_dequantize(const int32_t *rec, int64_t c, int64_t n_per_c, const double *mults, double q,
+                    double *out) {
+    for (int64_t k = 0; k < c; k++)
+        for (int64_t t = 0; t < n_per_c; t++) {
+            double v = (double)rec[k * n_per_c + t];
+            if (mults) v = v / mults[k];
+            out[k * n_per_c + t] = v / q;
+        }
+}
+
+/* output image size of waverec2 for (H,W,F,level): sizes follow the trim rule */
+void orc_waverec2_shape(int64_t H, int64_t W, int F, int level, int64_t *Ho, int64_t *Wo) {
+    int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
+    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int64_t ah = ll_h, aw = ll_w;
+    for (int l = L; l >= 1; l--) {
+        if (ah == hs[l] + 1) ah--;
+        if (aw == ws[l] + 1) aw--;
+        ah = 2 * hs[l] - F + 2;
+        aw = 2 * ws[l] - F + 2;
+    }
+    *Ho = ah; *Wo = aw;
+}
+
+/* array_to_coeffs + waverec2 : wrapper:275-276.  out is [c,Ho,Wo] from orc_waverec2_shape. */
+int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int wid, int level,
+                       double *out) {
+    if (wid < 0 || wid >= NWAVELETS) return -1;
+    const wavelet_t *wv = &WAVELETS[wid];
+    int F = wv->F;
+    int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
+    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int64_t offh[64], offw[64];
+    int64_t ah0 = ll_h, aw0 = ll_w;
+    for (int l = L; l >= 1; l--) { offh[l] = ah0; offw[l] = aw0; ah0 += hs[l]; aw0 += ws[l]; }
+    int64_t Ho, Wo;
+    orc_waverec2_shape(H, W, F, level, &Ho, &Wo);
+    for (int64_t k = 0; k < c; k++) {
+        const double *in = arr + k * eh * ew;
+        int64_t ah = ll_h, aw = ll_w;
+        double *a = (double *)malloc(sizeof(double) * ah * aw);
+        if (!a) return -2;
+        for (int64_t i = 0; i < ah; i++)
+            for (int64_t j = 0; j < aw; j++) a[i * aw + j] = in[i * ew + j];
+        for (int l = L; l >= 1; l--) {
+            int64_t h2 = hs[l], w2 = ws[l];
+            /* trim rule (_multilevel.py waverec2): a_len == d_len + 1 -> drop last */
+            int64_t uh = (ah == h2 + 1) ? ah - 1 : ah, uw = (aw == w2 + 1) ? aw - 1 : aw;
+            if (uh != h2 || uw != w2) { free(a); return -3; }
+            int64_t wo = 2 * w2 - F + 2, ho = 2 * h2 - F + 2;
+            /* axis -1 first: (aa,ad) -> lo rows ; (da,dd) -> hi rows */
+            double *tl = (double *)malloc(sizeof(double) * h2 * wo), *th = (double *)malloc(sizeof(double) * h2 * wo);
+            double *rowd = (double *)malloc(sizeof(double) * w2 * 3);
+            double *nx = (double *)malloc(sizeof(double) * ho * wo);
+            if (!tl || !th || !rowd || !nx) { free(tl); free(th); free(rowd); free(nx); free(a); return -2; }
+            for (int64_t i = 0; i < h2; i++) {
+                const double *ad = in + i * ew + offw[l];
+                const double *da = in + (offh[l] + i) * ew;
+                const double *dd = in + (offh[l] + i) * ew + offw[l];
+                idwt_line(a + i * aw, ad, w2, 1, wv->rec_lo, wv->rec_hi, F, tl + i * wo, 1);
+                idwt_line(da, dd, w2, 1, wv->rec_lo, wv->rec_hi, F, th + i * wo, 1);
+            }
+            for (int64_t j = 0; j < wo; j++)
+                idwt_line(tl + j, th + j, h2, wo, wv->rec_lo, wv->rec_hi, F, nx + j, wo);
+            free(tl); free(th); free(rowd); free(a);
+            a = nx; ah = ho; aw = wo;
+        }
+        memcpy(out + k * Ho * Wo, a, sizeof(double) * Ho * Wo);
+        free(a);
+    }
+    return 0;
+}

@@ -1,0 +1,213 @@
+"""Golden-vector capture (run ONLY in the build container, never on the GPU box).
+
+Imports the reference in place from /root/reference (nothing is copied) with
+in-memory stand-ins for the two modules that cannot exist here (the un-built
+Rust extension `spiht.spiht` and the absent `colour` package), runs it on small
+seeded inputs and stores inputs + outputs as .npz fixtures next to this file.
+
+  part "loops"   (any interpreter)             spiht/spiht_py.py encode/decode list logic on
+                                               int32 arrays (pywt stubbed as pass-through)
+                                               -> spiht_py_loops.npz
+  part "wrapper" (/opt/conda/bin/python3.9,    spiht/spiht_wrapper.py front half (pixels -> int32
+                  real PyWavelets 1.1.1)       coefficients handed to the Rust boundary), back half
+                                               (int32 rec array -> pixels), geometry, filter banks
+                                               -> wrapper_pywt.npz
+
+usage:
+  PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py loops
+  PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py wrapper
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+
+
+def synth_image(seed, c, H, W):
+    """SURVEY.md 8(d) pixel-domain generator (1/f^2-like, uint8-rounded, /255)."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((c, H, W))
+    b = np.cumsum(np.cumsum(g, axis=1), axis=2)
+    mn = b.min(axis=(1, 2), keepdims=True)
+    mx = b.max(axis=(1, 2), keepdims=True)
+    b = (b - mn) / (mx - mn)
+    b = b + 0.02 * rng.standard_normal((c, H, W))
+    return np.round(np.clip(b, 0, 1) * 255).astype(np.uint8) / 255
+
+
+def synth_coeffs(seed, c, h, w, ll_h, ll_w, scale=3000.0):
+    """SURVEY.md 8(d) coefficient-domain generator."""
+    rng = np.random.default_rng(seed)
+    i = np.arange(h)[:, None]
+    j = np.arange(w)[None, :]
+    t = np.maximum(0, np.ceil(np.log2(np.maximum((i + 1) / ll_h, (j + 1) / ll_w))))
+    sc = scale * 2.0 ** (-1.3 * t)
+    return np.trunc(rng.laplace(0, 1, (c, h, w)) * sc[None]).astype(np.int32)
+
+
+def _stub_common():
+    sys.path.insert(0, REF)
+    col = types.ModuleType("colour")
+    col.COLOURSPACE_MODELS = ("RGB", "IPT")
+    sys.modules["colour"] = col
+
+
+def part_loops():
+    _stub_common()
+    ext = types.ModuleType("spiht.spiht")
+    ext.encode = ext.decode = None
+    sys.modules["spiht.spiht"] = ext
+    sys.modules["pywt"] = types.ModuleType("pywt")  # pass-through; replaced below
+    import spiht.spiht_py as sp
+    from collections import namedtuple
+
+    sp.EncodingResult = namedtuple(
+        "ER", "encoded_bytes h w c max_n ll_h ll_w wavelet quantization_scale slices mode")
+
+    class _LL:
+        def __init__(s, shape):
+            s.shape = shape
+
+    st = {}
+    sp.pywt.wavedec2 = lambda image, wavelet=None, level=None, mode=None: [
+        _LL((image.shape[0], st["ll_h"], st["ll_w"])), image]
+    sp.pywt.coeffs_to_array = lambda coeffs, axes=None: (
+        coeffs[1].astype(np.float64), [(slice(None), slice(0, st["ll_h"]), slice(0, st["ll_w"]))])
+    sp.pywt.array_to_coeffs = lambda arr, slices, output_format=None: arr
+    sp.pywt.waverec2 = lambda coeffs, mode=None, wavelet=None: coeffs
+
+    cases = []
+    rng = np.random.default_rng(7)
+    # (c,h,w,ll_h,ll_w,max_bits) -- dyadic, odd sizes (Q3), odd LL (Q4), shallow trees (Q5)
+    shapes = [(1, 8, 8, 2, 2, 4000), (1, 16, 16, 2, 2, 10000), (2, 16, 16, 4, 4, 3000),
+              (3, 13, 17, 3, 5, 20000), (1, 21, 19, 5, 3, 20000), (3, 24, 40, 3, 5, 2500),
+              (1, 32, 32, 2, 2, 777), (2, 11, 23, 4, 6, 20000), (1, 4, 4, 2, 2, 500),
+              (3, 33, 29, 6, 5, 6001), (1, 8, 8, 4, 4, 3000), (1, 6, 6, 3, 3, 3000)]
+    for idx, (c, h, w, lh, lw, mb) in enumerate(shapes):
+        if idx % 2 == 0:
+            arr = synth_coeffs(100 + idx, c, h, w, lh, lw, scale=300.0)
+        else:
+            arr = rng.normal(0, 16, (c, h, w)).astype(np.int32)
+        if idx == 1:
+            arr = 32 * np.ones((c, h, w), np.int32)  # simple_test_encode input (encoder_decoder.rs:865-875)
+        if int(np.abs(arr).max()) == 0:
+            arr[0, 0, 0] = 5
+        st.update(ll_h=lh, ll_w=lw)
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = sp.encode_image_py(arr, level=None, max_bits=mb, quantization_scale=1)
+            rec = sp.decode_image_py(r)
+        bits = np.array([int(b) for b in r.encoded_bytes], dtype=np.uint8)  # zero-filled to max_bits
+        cases.append(dict(arr=arr, ll_h=lh, ll_w=lw, max_bits=mb, bits=bits, max_n=int(r.max_n),
+                          rec=np.asarray(rec).astype(np.int32)))
+    # helper known answers straight from the reference functions
+    helpers = dict(
+        set_bit=np.array([[x, n, b, sp.set_bit(x, n, b)] for x, n, b in
+                          [(-96, 5, 0), (-96, 5, 1), (-64, 5, 1), (96, 5, 1), (96, 5, 0), (7, 0, 0), (-7, 3, 1)]],
+                         dtype=np.int64),
+        offspring=np.array([[i, j, h, w, lh, lw] + [v for o in (sp.get_offspring(i, j, h, w, lh, lw) or [(-1, -1)] * 4)
+                                                    for v in o]
+                            for (i, j, h, w, lh, lw) in
+                            [(0, 0, 16, 16, 2, 2), (0, 1, 16, 16, 2, 2), (1, 0, 16, 16, 2, 2), (1, 1, 16, 16, 2, 2),
+                             (2, 4, 13, 17, 3, 5), (2, 3, 13, 17, 3, 5), (5, 7, 13, 17, 3, 5), (6, 8, 13, 17, 3, 5),
+                             (3, 3, 16, 16, 2, 2), (7, 7, 16, 16, 2, 2), (8, 1, 16, 16, 2, 2), (12, 18, 1111, 1949, 13, 19)]],
+                           dtype=np.int64))
+    out = {}
+    for n, cs in enumerate(cases):
+        for k, v in cs.items():
+            out["case%02d_%s" % (n, k)] = np.asarray(v)
+    out["ncases"] = np.array(len(cases))
+    out.update({"helper_" + k: v for k, v in helpers.items()})
+    np.savez_compressed(os.path.join(HERE, "spiht_py_loops.npz"), **out)
+    print("wrote spiht_py_loops.npz:", len(cases), "cases")
+
+
+def part_wrapper():
+    _stub_common()
+    cap = {}
+    ext = types.ModuleType("spiht.spiht")
+
+    def _enc(arr, ll_h, ll_w, mb):
+        cap.update(arr=np.array(arr, copy=True), ll_h=ll_h, ll_w=ll_w, max_bits=mb)
+        return b"", 0
+
+    ext.encode = _enc
+    ext.decode = None
+    sys.modules["spiht.spiht"] = ext
+    import pywt
+    from spiht.spiht_wrapper import SpihtSettings, encode_image, decode_from_rec_arr, get_slices_and_h_w
+
+    out = {"pywt_version": np.array(pywt.__version__)}
+    for name in ["bior2.2", "bior4.4", "bior6.8", "haar"]:
+        fb = pywt.Wavelet(name).filter_bank
+        out["fb_" + name] = np.array(fb, dtype=np.float64)
+
+    # geometry: the five BASELINE configs + a sweep of odd/even shapes
+    geo = []
+    geo_cases = [(512, 512, "bior2.2", 5), (1080, 1920, "bior2.2", 7), (1024, 1024, "bior2.2", None),
+                 (4096, 4096, "bior6.8", 9), (256, 342, "bior2.2", None), (256, 511, "bior2.2", None),
+                 (289, 206, "bior4.4", None), (33, 47, "bior2.2", 2), (64, 64, "bior4.4", 3),
+                 (100, 37, "bior6.8", 1), (75, 75, "haar", 3), (1024, 768, "bior2.2", 6)]
+    for (H, W, wv, lv) in geo_cases:
+        s = SpihtSettings(wavelet=wv)
+        slices, eh, ew = get_slices_and_h_w(H, W, s, lv)
+        nlev = len(slices) - 1
+        geo.append([H, W, ["bior2.2", "bior4.4", "bior6.8", "haar"].index(wv), -1 if lv is None else lv,
+                    slices[0][1].stop, slices[0][2].stop, eh, ew, nlev])
+    out["geometry"] = np.array(geo, dtype=np.int64)
+
+    # front half + back half
+    cases = [
+        dict(c=1, H=32, W=32, wavelet="bior2.2", mode="reflect", level=2, q=50.0, mults=None),
+        dict(c=3, H=48, W=64, wavelet="bior2.2", mode="reflect", level=None, q=50.0, mults=None),
+        dict(c=3, H=37, W=53, wavelet="bior2.2", mode="reflect", level=2, q=50.0, mults=None),
+        dict(c=3, H=64, W=96, wavelet="bior2.2", mode="reflect", level=3, q=1.0, mults=[100.0, 20.0, 20.0]),
+        dict(c=1, H=96, W=128, wavelet="bior4.4", mode="symmetric", level=None, q=50.0, mults=None),
+        dict(c=2, H=45, W=70, wavelet="bior4.4", mode="symmetric", level=2, q=255.0, mults=[1.0, 0.2]),
+        dict(c=1, H=160, W=144, wavelet="bior6.8", mode="reflect", level=None, q=50.0, mults=None),
+        dict(c=1, H=80, W=80, wavelet="bior6.8", mode="reflect", level=4, q=50.0, mults=None),  # level > max (Q13)
+        dict(c=1, H=40, W=56, wavelet="haar", mode="reflect", level=3, q=50.0, mults=None),
+        dict(c=1, H=50, W=41, wavelet="bior2.2", mode="periodic", level=2, q=50.0, mults=None),
+        dict(c=1, H=50, W=41, wavelet="bior2.2", mode="zero", level=2, q=50.0, mults=None),
+        dict(c=1, H=50, W=41, wavelet="bior2.2", mode="constant", level=2, q=50.0, mults=None),
+        dict(c=3, H=120, W=200, wavelet="bior2.2", mode="reflect", level=4, q=50.0, mults=None),
+    ]
+    rng = np.random.default_rng(11)
+    for n, cs in enumerate(cases):
+        img = synth_image(1000 + n, cs["c"], cs["H"], cs["W"])
+        s = SpihtSettings(wavelet=cs["wavelet"], quantization_scale=cs["q"], mode=cs["mode"],
+                          per_channel_quant_scales=cs["mults"])
+        encode_image(img, s, level=cs["level"], max_bits=None)
+        coeffs = cap["arr"]
+        # float (unquantised) packed array for tolerance checks of the DWT alone
+        co = pywt.wavedec2(img, wavelet=cs["wavelet"], level=cs["level"], mode=cs["mode"])
+        farr, _ = pywt.coeffs_to_array(co, axes=(-2, -1))
+        # back half on a perturbed rec array (as a truncated decode would give)
+        rec = (coeffs - (coeffs % 4) * (rng.random(coeffs.shape) < 0.5)).astype(np.int32)
+        rec_img = decode_from_rec_arr(rec, cs["H"], cs["W"], cs["level"], s)
+        p = "case%02d_" % n
+        out[p + "img"] = img
+        out[p + "coeffs"] = coeffs
+        out[p + "farr"] = farr
+        out[p + "ll"] = np.array([cap["ll_h"], cap["ll_w"]])
+        out[p + "max_bits"] = np.array(cap["max_bits"], dtype=np.uint64)
+        out[p + "rec"] = rec
+        out[p + "rec_img"] = rec_img
+        out[p + "meta"] = np.array([cs["c"], cs["H"], cs["W"], -1 if cs["level"] is None else cs["level"]])
+        out[p + "wavelet"] = np.array(cs["wavelet"])
+        out[p + "mode"] = np.array(cs["mode"])
+        out[p + "q"] = np.array(cs["q"])
+        out[p + "mults"] = np.array(cs["mults"] if cs["mults"] else [], dtype=np.float64)
+    out["ncases"] = np.array(len(cases))
+    np.savez_compressed(os.path.join(HERE, "wrapper_pywt.npz"), **out)
+    print("wrote wrapper_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
+
+
+if __name__ == "__main__":
+    {"loops": part_loops, "wrapper": part_wrapper}[sys.argv[1]]()
