@@ -1,0 +1,160 @@
+/*
+ * spiht_hip.h -- C ABI of libspiht_hip.so, the MI355X (gfx950) SPIHT hot path.
+ *
+ * This is the drop-in boundary: the entry points are what the reference's
+ * extension module `spiht.spiht` (PyO3, /root/reference/src/lib.rs) exposes,
+ * re-expressed with plain pointers and sizes, plus batched / fused forms so the
+ * DWT output never has to leave HBM.  No torch types, no C++ types.
+ *
+ * Every function returns an int status (SPIHT_OK = 0) and never aborts.
+ * Host pointers unless a parameter says "device".
+ */
+#ifndef SPIHT_HIP_H
+#define SPIHT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SPIHT_OK = 0,
+    SPIHT_ERR_LL = 1,        /* ll_h <= 1 || ll_w <= 1: the reference asserts (encoder_decoder.rs:160-161, 310-311) */
+    SPIHT_ERR_EMPTY = 2,     /* empty array: the reference unwrap()s None (encoder_decoder.rs:165) */
+    SPIHT_ERR_SHAPE = 3,     /* LL offspring fall outside [h,w]: the reference panics on an out-of-bounds index */
+    SPIHT_ERR_CAPACITY = 4,  /* caller's output buffer too small; *out_nbits holds the size needed */
+    SPIHT_ERR_HIP = 5,       /* a HIP runtime call failed; see spiht_last_hip_error() */
+    SPIHT_ERR_ARG = 6,       /* null pointer / negative size / unknown wavelet or mode */
+    SPIHT_ERR_MAGNITUDE = 7, /* max|x| >= 2^30: outside the range the reference handles */
+    SPIHT_ERR_INTERNAL = 8,  /* device-side list overflow guard tripped (a bug, never expected) */
+    SPIHT_ERR_TOO_LARGE = 9, /* c*h*w >= 2^31 or stream >= 2^32 bits */
+    SPIHT_ERR_NOMEM = 10
+};
+
+/* signal extension modes of the DWT (pywt names) */
+enum { SPIHT_MODE_REFLECT = 0, SPIHT_MODE_SYMMETRIC = 1, SPIHT_MODE_PERIODIC = 2, SPIHT_MODE_ZERO = 3,
+       SPIHT_MODE_CONSTANT = 4 };
+
+#define SPIHT_MAX_BITS_UNLIMITED 0xFFFFFFFFFFFFFFFFull
+
+typedef struct spiht_ctx spiht_ctx;
+
+const char *spiht_strerror(int status);
+const char *spiht_last_hip_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int spiht_abi_version(void);
+
+/* One context per (process, GPU): device id, streams, scratch.  Thread-safe per context
+ * (calls on one context are serialised by an internal mutex); no globals survive a call. */
+int spiht_ctx_create(int device, spiht_ctx **out);
+void spiht_ctx_destroy(spiht_ctx *ctx);
+/* Block until everything queued on the context's stream has finished. */
+int spiht_ctx_synchronize(spiht_ctx *ctx);
+/* Stage timing: when enabled, HIP events bracket each kernel group of the next calls
+ * (on the context's own stream); spiht_ctx_get_timing returns accumulated ms and launches. */
+int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled);
+int spiht_ctx_reset_timing(spiht_ctx *ctx);
+int spiht_ctx_num_stages(void);
+const char *spiht_ctx_stage_name(int stage);
+int spiht_ctx_get_timing(spiht_ctx *ctx, int stage, double *ms, uint64_t *launches);
+
+/* ---------------------------------------------------------------------------------------
+ * L2 boundary, single image, host buffers.
+ * ------------------------------------------------------------------------------------- */
+
+/* Replaces `encode(x, ll_h, ll_w, max_bits) -> (bytes, max_n)`  (src/lib.rs:24-32, which calls
+ * encoder_decoder.rs:155-303 and packs bits LSB-first, lib.rs:29).
+ * x: int32 [c,h,w] with element strides (any strides, as PyReadonlyArray3 allows).
+ * max_bits: 0 behaves as "never reached" exactly like the reference (encoder_decoder.rs:196).
+ * out/out_cap: caller-owned byte buffer; on SPIHT_ERR_CAPACITY *out_nbits is the bit count needed. */
+int spiht_encode_i32(spiht_ctx *ctx, const int32_t *x, int64_t c, int64_t h, int64_t w, int64_t stride_c,
+                     int64_t stride_h, int64_t stride_w, int64_t ll_h, int64_t ll_w, uint64_t max_bits,
+                     uint8_t *out, uint64_t out_cap, uint64_t *out_nbits, uint8_t *max_n);
+
+/* Upper bound, in bytes, of the stream spiht_encode_i32 can produce for this geometry when the largest
+ * magnitude is max_abs (pass 0x3FFFFFFF if unknown).  Used by bindings to size `out`. */
+int spiht_encode_bound(int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, uint32_t max_abs,
+                       uint64_t max_bits, uint64_t *bound_bytes);
+
+/* Replaces `decode(data_u8, n, c, h, w, ll_h, ll_w) -> ndarray[int32,(c,h,w)]`  (src/lib.rs:35-42 ->
+ * encoder_decoder.rs:307-454).  All 8*nbytes bits are data (lib.rs:38).  out: c*h*w int32, C-contiguous,
+ * fully written (zeros where nothing was decoded). */
+int spiht_decode_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
+                     int64_t w, int64_t ll_h, int64_t ll_w, int32_t *out);
+
+/* ---------------------------------------------------------------------------------------
+ * Batched, device-resident forms (new; the reference codes one image per call).
+ * All pointers below are DEVICE pointers (hipMalloc'd by anyone, e.g. a torch tensor's data_ptr()).
+ * Work is queued on the context's stream; call spiht_ctx_synchronize() before reading results.
+ * ------------------------------------------------------------------------------------- */
+
+/* B images of identical geometry. d_x: int32 [B,c,h,w] contiguous.
+ * d_out: B slots of slot_stride bytes (multiple of 4, >= ceil(min(max_bits,bound)/8) rounded up to 4);
+ * bytes past ceil(nbits/8) in a slot are zeroed.  d_nbits: uint64 [B].  d_max_n: uint8 [B]. */
+int spiht_encode_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
+                           int64_t ll_h, int64_t ll_w, uint64_t max_bits, uint8_t *d_out, uint64_t slot_stride,
+                           uint64_t *d_nbits, uint8_t *d_max_n);
+
+/* d_data: B slots of slot_stride bytes (multiple of 4); d_nbytes: uint64 [B] valid bytes per slot
+ * (all 8*nbytes bits are data); d_max_n: uint8 [B]; d_out: int32 [B,c,h,w], fully written. */
+int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
+                           const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
+                           int64_t ll_w, int32_t *d_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Fused image path: pixels -> DWT -> quantise -> SPIHT and back, everything in HBM.
+ * Mirrors spiht_wrapper.encode_image / decode_image (wrapper:142-216) without colour conversion.
+ * ------------------------------------------------------------------------------------- */
+
+/* Geometry of the packed coefficient array for an H x W image (wrapper:92-139, pywt.wavedecn_shapes).
+ * level < 0 means "None" (pywt's maximum useful level).  Any out pointer may be NULL. */
+int spiht_wavelet_id(const char *name);           /* "bior2.2", "bior4.4", "bior6.8", "haar"/"db1"; <0 if unknown */
+int spiht_mode_id(const char *name);              /* "reflect", "symmetric", "periodic", "zero", "constant"; <0 if unknown */
+int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h, int64_t *ll_w,
+                   int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W);
+
+/* d_img: float64 [B,c,H,W] (device).  channel_mults: HOST array of c doubles or NULL
+ * (SpihtSettings.per_channel_quant_scales); q_scale: SpihtSettings.quantization_scale.
+ * Outputs as spiht_encode_batch_i32.  d_coeffs: optional device int32 [B,c,enc_h,enc_w] that receives the
+ * quantised coefficient array handed to the coder (NULL to keep it in scratch). */
+int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                 int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                 uint64_t max_bits, uint8_t *d_out, uint64_t slot_stride, uint64_t *d_nbits,
+                                 uint8_t *d_max_n, int32_t *d_coeffs);
+
+/* Inverse: streams -> float64 [B,c,rec_H,rec_W] (rec_H/rec_W from spiht_geometry; may exceed H/W by one on
+ * odd axes exactly as pywt.waverec2 does).  d_rec: optional device int32 [B,c,enc_h,enc_w] receiving the
+ * decoded coefficient array. */
+int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
+                                 const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c, int64_t H,
+                                 int64_t W, int wavelet, int mode, int level, double q_scale,
+                                 const double *channel_mults, double *d_img_out, int32_t *d_rec);
+
+/* DWT halves on their own (device pointers), for parity tests and profiling:
+ * forward: float64 [B,c,H,W] -> int32 [B,c,enc_h,enc_w] (quantised, zero padded)  (wrapper:163-172)
+ * inverse: int32 [B,c,enc_h,enc_w] -> float64 [B,c,rec_H,rec_W]                   (wrapper:259-276) */
+int spiht_dwt_quant_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                              int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                              int32_t *d_coeffs);
+int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H, int64_t W,
+                                 int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                 double *d_img_out);
+
+/* Significance pyramid on its own (device pointers), for parity tests and profiling:
+ * d_x int32 [B,c,h,w] -> d_dmsb, d_lmsb uint8 [B,c,h,w] (1 + msb of the D / L set maxima of the node with
+ * that index, 0 = empty/zero; only nodes with offspring are written) and d_maxabs uint32 [B]. */
+int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
+                            int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs);
+
+/* Thin device-memory helpers so a host language without a HIP binding can drive the batched API. */
+int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr);
+int spiht_dev_free(spiht_ctx *ctx, void *d_ptr);
+int spiht_dev_upload(spiht_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
+int spiht_dev_download(spiht_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
+int spiht_dev_memset(spiht_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPIHT_HIP_H */

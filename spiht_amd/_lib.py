@@ -1,0 +1,185 @@
+"""ctypes binding of libspiht_hip.so (include/spiht_hip.h).
+
+The HIP library is the only compute path of this package: if it is missing or cannot be loaded the
+import fails loudly -- there is no CPU fallback (the CPU restatement under oracle/ is test
+infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspiht_hip.so")
+
+OK, ERR_LL, ERR_EMPTY, ERR_SHAPE, ERR_CAPACITY, ERR_HIP, ERR_ARG, ERR_MAGNITUDE, ERR_INTERNAL, ERR_TOO_LARGE, \
+    ERR_NOMEM = range(11)
+
+MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4}
+
+
+class SpihtHipError(RuntimeError):
+    """A HIP runtime failure or an internal guard of libspiht_hip."""
+
+
+class PanicException(BaseException):
+    """Counterpart of pyo3_runtime.PanicException, which the reference raises when the Rust core panics
+    (assert!(ll_h > 1), encoder_decoder.rs:160-161; out-of-bounds index; unwrap on an empty array).
+    Like PyO3's, it derives from BaseException."""
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# every symbol include/spiht_hip.h declares
+SYMBOLS = [
+    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
+    "spiht_ctx_synchronize", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
+    "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
+    "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
+    "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
+    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_dev_alloc", "spiht_dev_free",
+    "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset",
+]
+
+
+def lib():
+    """Load libspiht_hip.so (once).  Raises ImportError if it has not been built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libspiht_hip.so is missing (%s): build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C spiht_amd/csrc`; spiht_amd has no CPU fallback" % LIB_PATH)
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise ImportError("cannot load %s: %s" % (LIB_PATH, e))
+        i64, u64, u8, i32 = C.c_int64, C.c_uint64, C.c_uint8, C.c_int
+        vp = C.c_void_p
+        L.spiht_strerror.restype = C.c_char_p
+        L.spiht_strerror.argtypes = [i32]
+        L.spiht_last_hip_error.restype = C.c_char_p
+        L.spiht_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.spiht_ctx_destroy.argtypes = [vp]
+        L.spiht_ctx_destroy.restype = None
+        L.spiht_ctx_synchronize.argtypes = [vp]
+        L.spiht_ctx_set_timing.argtypes = [vp, i32]
+        L.spiht_ctx_reset_timing.argtypes = [vp]
+        L.spiht_ctx_stage_name.restype = C.c_char_p
+        L.spiht_ctx_stage_name.argtypes = [i32]
+        L.spiht_ctx_get_timing.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(u64)]
+        L.spiht_encode_i32.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, u64, vp, u64, C.POINTER(u64),
+                                       C.POINTER(u8)]
+        L.spiht_encode_bound.argtypes = [i64, i64, i64, i64, i64, C.c_uint32, u64, C.POINTER(u64)]
+        L.spiht_decode_i32.argtypes = [vp, vp, u64, u8, i64, i64, i64, i64, i64, vp]
+        L.spiht_encode_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, u64, vp, u64, vp, vp]
+        L.spiht_decode_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
+        L.spiht_wavelet_id.argtypes = [C.c_char_p]
+        L.spiht_mode_id.argtypes = [C.c_char_p]
+        L.spiht_geometry.argtypes = [i64, i64, i32, i32, C.POINTER(i32)] + [C.POINTER(i64)] * 6
+        L.spiht_encode_image_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, vp,
+                                                   u64, vp, vp, vp]
+        L.spiht_decode_image_batch_f64.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double,
+                                                   vp, vp, vp]
+        L.spiht_dwt_quant_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_dequant_idwt_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_pyramid_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp]
+        L.spiht_dev_alloc.argtypes = [vp, u64, C.POINTER(vp)]
+        L.spiht_dev_free.argtypes = [vp, vp]
+        L.spiht_dev_upload.argtypes = [vp, vp, vp, u64]
+        L.spiht_dev_download.argtypes = [vp, vp, vp, u64]
+        L.spiht_dev_memset.argtypes = [vp, vp, i32, u64]
+        _lib = L
+        return _lib
+
+
+def check(status):
+    """Map a C status to the exception the reference would raise."""
+    if status == OK:
+        return
+    L = lib()
+    msg = L.spiht_strerror(status).decode()
+    if status in (ERR_LL, ERR_EMPTY, ERR_SHAPE):
+        raise PanicException(msg)
+    if status == ERR_HIP:
+        raise SpihtHipError("%s: %s" % (msg, L.spiht_last_hip_error().decode()))
+    if status in (ERR_INTERNAL, ERR_NOMEM):
+        raise SpihtHipError(msg)
+    if status == ERR_TOO_LARGE:
+        raise OverflowError(msg)
+    raise ValueError(msg)
+
+
+class Context:
+    """One spiht_ctx (device id, stream, scratch).  Created lazily, one per device."""
+
+    def __init__(self, device=0):
+        self._lib = lib()
+        h = C.c_void_p()
+        check(self._lib.spiht_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.spiht_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self._lib.spiht_ctx_synchronize(self.handle))
+
+    # stage timing (HIP events on the context's stream)
+    def set_timing(self, on):
+        check(self._lib.spiht_ctx_set_timing(self.handle, 1 if on else 0))
+
+    def reset_timing(self):
+        check(self._lib.spiht_ctx_reset_timing(self.handle))
+
+    def timing(self):
+        out = {}
+        for s in range(self._lib.spiht_ctx_num_stages()):
+            ms, n = C.c_double(), C.c_uint64()
+            check(self._lib.spiht_ctx_get_timing(self.handle, s, C.byref(ms), C.byref(n)))
+            out[self._lib.spiht_ctx_stage_name(s).decode()] = (ms.value, n.value)
+        return out
+
+    # device memory helpers
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self._lib.spiht_dev_alloc(self.handle, int(nbytes), C.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        check(self._lib.spiht_dev_free(self.handle, C.c_void_p(ptr)))
+
+    def upload(self, dptr, arr):
+        check(self._lib.spiht_dev_upload(self.handle, C.c_void_p(dptr), C.c_void_p(arr.ctypes.data), arr.nbytes))
+
+    def download(self, arr, dptr):
+        check(self._lib.spiht_dev_download(self.handle, C.c_void_p(arr.ctypes.data), C.c_void_p(dptr), arr.nbytes))
+
+    def memset(self, dptr, value, nbytes):
+        check(self._lib.spiht_dev_memset(self.handle, C.c_void_p(dptr), int(value), int(nbytes)))
+
+
+_ctxs = {}
+_ctx_lock = threading.Lock()
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("SPIHT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _ctx_lock:
+        c = _ctxs.get(device)
+        if c is None or c.handle is None:
+            c = Context(device)
+            _ctxs[device] = c
+        return c

@@ -1,0 +1,984 @@
+// C ABI of libspiht_hip.so (include/spiht_hip.h): context, scratch, geometry and the host side of the
+// encode/decode entry points.  Mirrors what /root/reference/src/lib.rs does around encode()/decode():
+// take a strided int32 view, run the coder, pack/unpack bytes -- here by queueing HIP kernels.
+#include "../../include/spiht_hip.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "wavelets.h"
+
+extern "C" {
+int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st);
+int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
+int spiht_launch_encode(const EncArgs *a, hipStream_t st);
+int spiht_launch_decode(const DecArgs *a, hipStream_t st);
+int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
+int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
+int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
+                             double q, hipStream_t st);
+int spiht_launch_dequant_plain(const int32_t *in, double *out, size_t n_per_plane, int planes, int c,
+                               const double *mults, double q, hipStream_t st);
+}
+
+static thread_local std::string g_hip_err;
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return SPIHT_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+#define LAUNCHCHK(expr)                                                                    \
+    do {                                                                                   \
+        int _e = (expr);                                                                   \
+        if (_e != 0) {                                                                     \
+            g_hip_err = std::string(#expr) + ": launch error " + std::to_string(_e);       \
+            return SPIHT_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+#define CHK(expr)                      \
+    do {                               \
+        int _s = (expr);               \
+        if (_s != SPIHT_OK) return _s; \
+    } while (0)
+
+enum Stage {
+    ST_H2D = 0, ST_D2H, ST_ABSMAX, ST_PYRAMID, ST_ENC_LISTS, ST_DEC_LISTS, ST_DWT_L1, ST_DWT_REST, ST_IDWT_REST,
+    ST_IDWT_L1, ST_MEMSET, ST_COUNT
+};
+static const char *STAGE_NAMES[ST_COUNT] = {"h2d", "d2h", "absmax", "pyramid", "encode_lists", "decode_lists",
+                                            "dwt_level1", "dwt_rest", "idwt_rest", "idwt_level1", "memset"};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct spiht_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    int num_cu = 256;
+    float log2_thresh[32];
+    // grow-only scratch
+    DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
+    // timing
+    bool timing = false;
+    struct Rec { int stage; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ST_COUNT];
+    uint64_t launches[ST_COUNT];
+};
+
+static int ensure(spiht_ctx *ctx, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return SPIHT_OK;
+    if (b.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        want = bytes;
+        e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+            b.p = nullptr;
+            return SPIHT_ERR_NOMEM;
+        }
+    }
+    b.cap = want;
+    return SPIHT_OK;
+}
+
+struct StageTimer {
+    spiht_ctx *ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(spiht_ctx *c, int s) : ctx(c), stage(s) {
+        if (!ctx->timing) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->pool.empty()) { e = ctx->pool.back(); ctx->pool.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = get();
+        b = get();
+        if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~StageTimer() {
+        if (!ctx->timing || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({stage, a, b});
+    }
+};
+
+static void drain_timing(spiht_ctx *ctx) {
+    if (ctx->pending.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ctx->ms[r.stage] += ms;
+            ctx->launches[r.stage] += 1;
+        }
+        ctx->pool.push_back(r.a);
+        ctx->pool.push_back(r.b);
+    }
+    ctx->pending.clear();
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry
+// ------------------------------------------------------------------------------------------------
+
+static int dwt_max_level(int64_t len, int F) {  // pywt common.c dwt_max_level
+    if (F <= 1 || len < F - 1) return 0;
+    int64_t q = len / (F - 1);
+    int l = 0;
+    while (q > 1) { q >>= 1; l++; }
+    return l;
+}
+
+struct ImgGeom {
+    int L;
+    int64_t hs[SPIHT_MAX_LEVELS + 1], ws[SPIHT_MAX_LEVELS + 1];      // band sizes, [0] = image
+    int64_t offh[SPIHT_MAX_LEVELS + 1], offw[SPIHT_MAX_LEVELS + 1];  // detail block offsets per level
+    int64_t ll_h, ll_w, enc_h, enc_w, rec_H, rec_W;
+};
+
+static int img_geometry(int64_t H, int64_t W, int F, int level, ImgGeom *g) {
+    if (H < 1 || W < 1) return SPIHT_ERR_ARG;
+    int L = level;
+    if (L < 0) L = std::min(dwt_max_level(H, F), dwt_max_level(W, F));
+    if (L > SPIHT_MAX_LEVELS) return SPIHT_ERR_ARG;
+    g->L = L;
+    g->hs[0] = H;
+    g->ws[0] = W;
+    for (int l = 1; l <= L; l++) {
+        g->hs[l] = (g->hs[l - 1] + F - 1) / 2;
+        g->ws[l] = (g->ws[l - 1] + F - 1) / 2;
+    }
+    g->ll_h = g->hs[L];
+    g->ll_w = g->ws[L];
+    int64_t ah = g->ll_h, aw = g->ll_w;
+    for (int l = L; l >= 1; l--) {
+        g->offh[l] = ah;
+        g->offw[l] = aw;
+        ah += g->hs[l];
+        aw += g->ws[l];
+    }
+    g->enc_h = ah;
+    g->enc_w = aw;
+    int64_t rh = g->ll_h, rw = g->ll_w;
+    for (int l = L; l >= 1; l--) {
+        rh = 2 * g->hs[l] - F + 2;
+        rw = 2 * g->ws[l] - F + 2;
+    }
+    g->rec_H = rh;
+    g->rec_W = rw;
+    return SPIHT_OK;
+}
+
+static int make_geom(int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, Geom *g) {
+    if (!(ll_h > 1) || !(ll_w > 1)) return SPIHT_ERR_LL;
+    if (c <= 0 || h <= 0 || w <= 0) return SPIHT_ERR_EMPTY;
+    // the reference indexes arr[(k, l, m)] for the offspring of every root node: out of bounds -> panic
+    int64_t need_h = (ll_h % 2 == 0) ? 2 * ll_h : 2 * ll_h - 1;
+    int64_t need_w = (ll_w % 2 == 0) ? 2 * ll_w : 2 * ll_w - 1;
+    if (h < need_h || w < need_w) return SPIHT_ERR_SHAPE;
+    if ((double)c * (double)h * (double)w >= 2147483648.0) return SPIHT_ERR_TOO_LARGE;
+    g->c = (int32_t)c; g->h = (int32_t)h; g->w = (int32_t)w;
+    g->ll_h = (int32_t)ll_h; g->ll_w = (int32_t)ll_w;
+    g->hw = (uint32_t)(h * w);
+    g->n = (uint32_t)(c * h * w);
+    g->pad = 0;
+    g->div_w = fastdiv_make((uint32_t)w);
+    g->div_hw = fastdiv_make(g->hw);
+    return SPIHT_OK;
+}
+
+// number of tree-node instances (duplicates counted) and of instances with offspring
+static void instance_counts(const Geom &g, uint64_t *nodes, uint64_t *parents) {
+    const uint64_t h = (uint64_t)g.h, w = (uint64_t)g.w;
+    const uint64_t he = h & ~1ull, we = w & ~1ull;  // (i|1) < h  <=>  i < he
+    const uint64_t hp = h / 2, wp = w / 2;          // has offspring <=> i < hp && j < wp
+    uint64_t nn = (uint64_t)g.ll_h * g.ll_w, pp = 0;
+    for (int64_t i = 0; i < g.ll_h; i++)
+        for (int64_t j = 0; j < g.ll_w; j++) {
+            if (i % 2 == 0 && j % 2 == 0) continue;
+            pp += 1;
+            uint64_t ri = (uint64_t)((i & 1) * g.ll_h + (i & ~1ll)), rj = (uint64_t)((j & 1) * g.ll_w + (j & ~1ll));
+            for (int q = 0; q < 4; q++) {
+                uint64_t ci = ri + (q >> 1), cj = rj + (q & 1);
+                // sub-tree of (ci,cj): depth t block rows [ci<<t, (ci+1)<<t)
+                for (int t = 0; t < 32; t++) {
+                    uint64_t r0 = ci << t, c0 = cj << t, sz = 1ull << t;
+                    uint64_t lim_h = t == 0 ? h : he, lim_w = t == 0 ? w : we;
+                    uint64_t rows = r0 >= lim_h ? 0 : std::min(sz, lim_h - r0);
+                    uint64_t cols = c0 >= lim_w ? 0 : std::min(sz, lim_w - c0);
+                    if (rows == 0 || cols == 0) break;
+                    nn += rows * cols;
+                    uint64_t prow = r0 >= hp ? 0 : std::min(sz, hp - r0);
+                    uint64_t pcol = c0 >= wp ? 0 : std::min(sz, wp - c0);
+                    pp += prow * pcol;
+                }
+            }
+        }
+    *nodes = nn * (uint64_t)g.c;
+    *parents = pp * (uint64_t)g.c;
+}
+
+static uint64_t bound_bits(const Geom &g, uint32_t max_abs) {
+    uint64_t nodes, parents;
+    instance_counts(g, &nodes, &parents);
+    int planes = 1;
+    while (planes < 32 && (1ull << planes) <= (uint64_t)max_abs) planes++;
+    planes += 1;  // Q1: the start plane can be one above the true msb
+    // per node: <= planes LIP zeros + sig + sign + <= planes refinement bits; per parent: <= planes A bits + planes B bits
+    return nodes * (2ull * planes + 2) + parents * (2ull * planes);
+}
+
+static void list_caps(const Geom &g, uint64_t max_bits, ListCaps *caps, uint64_t *nodes_out) {
+    uint64_t nodes, parents;
+    instance_counts(g, &nodes, &parents);
+    uint64_t roots = (uint64_t)g.c * g.ll_h * g.ll_w;
+    uint64_t mb = max_bits;
+    uint64_t lip = nodes, lsp = nodes, lis = parents;
+    if (mb < (1ull << 40)) {
+        lip = std::min(lip, roots + mb);
+        lsp = std::min(lsp, mb / 2 + 1);
+        lis = std::min(lis, roots + 4 * mb);
+    }
+    caps->lip = (uint32_t)std::min<uint64_t>(lip + 64, 0xFFFFFFF0ull);
+    caps->lsp = (uint32_t)std::min<uint64_t>(lsp + 64, 0xFFFFFFF0ull);
+    caps->lis = (uint32_t)std::min<uint64_t>(lis + 64, 0xFFFFFFF0ull);
+    caps->pad = 0;
+    if (nodes_out) *nodes_out = nodes;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+
+extern "C" const char *spiht_strerror(int s) {
+    switch (s) {
+    case SPIHT_OK: return "ok";
+    case SPIHT_ERR_LL: return "assertion failed: ll_h > 1 && ll_w > 1";
+    case SPIHT_ERR_EMPTY: return "empty coefficient array";
+    case SPIHT_ERR_SHAPE: return "offspring of the ll_h x ll_w root block fall outside the array (index out of bounds)";
+    case SPIHT_ERR_CAPACITY: return "output buffer too small";
+    case SPIHT_ERR_HIP: return "HIP runtime error";
+    case SPIHT_ERR_ARG: return "invalid argument";
+    case SPIHT_ERR_MAGNITUDE: return "coefficient magnitude >= 2^30 is outside the supported range";
+    case SPIHT_ERR_INTERNAL: return "internal list capacity guard tripped";
+    case SPIHT_ERR_TOO_LARGE: return "array or stream too large (c*h*w must be < 2^31, stream < 2^32 bits)";
+    case SPIHT_ERR_NOMEM: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+extern "C" const char *spiht_last_hip_error(void) { return g_hip_err.c_str(); }
+extern "C" int spiht_abi_version(void) { return 1; }
+
+extern "C" int spiht_ctx_create(int device, spiht_ctx **out) {
+    if (!out) return SPIHT_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        g_hip_err = "no such HIP device";
+        return SPIHT_ERR_HIP;
+    }
+    HIPCHK(hipSetDevice(device));
+    spiht_ctx *ctx = new spiht_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        delete ctx;
+        return SPIHT_ERR_HIP;
+    }
+    // `(max as f32).log2() as u8` with THIS host's libm (what Rust's f32::log2 lowers to on linux-gnu):
+    // thresh[k] = smallest float below 2^k whose truncated log2f already reads k
+    for (int k = 0; k < 32; k++) {
+        float t = ldexpf(1.0f, k);
+        if (k >= 1) {
+            float m = nextafterf(t, 0.0f);
+            int guard = 0;
+            while (guard++ < 64 && m >= 1.0f && (int)log2f(m) == k) { t = m; m = nextafterf(m, 0.0f); }
+        }
+        ctx->log2_thresh[k] = t;
+    }
+    for (int s = 0; s < ST_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
+    int rc = ensure(ctx, ctx->err, 256);
+    if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return SPIHT_OK;
+}
+
+extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
+                      &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
+                      &ctx->img};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : ctx->pool) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+extern "C" int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_timing(ctx);
+    ctx->timing = enabled != 0;
+    return SPIHT_OK;
+}
+extern "C" int spiht_ctx_reset_timing(spiht_ctx *ctx) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_timing(ctx);
+    for (int s = 0; s < ST_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
+    return SPIHT_OK;
+}
+extern "C" int spiht_ctx_num_stages(void) { return ST_COUNT; }
+extern "C" const char *spiht_ctx_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? STAGE_NAMES[s] : ""; }
+extern "C" int spiht_ctx_get_timing(spiht_ctx *ctx, int stage, double *ms, uint64_t *launches) {
+    if (!ctx || stage < 0 || stage >= ST_COUNT) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    drain_timing(ctx);
+    if (ms) *ms = ctx->ms[stage];
+    if (launches) *launches = ctx->launches[stage];
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side error word
+// ------------------------------------------------------------------------------------------------
+static int clear_err(spiht_ctx *ctx) {
+    HIPCHK(hipMemsetAsync(ctx->err.p, 0, 4, ctx->stream));
+    return SPIHT_OK;
+}
+static int read_err(spiht_ctx *ctx) {
+    uint32_t e = 0;
+    HIPCHK(hipMemcpyAsync(&e, ctx->err.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (e & 2u) return SPIHT_ERR_MAGNITUDE;
+    if (e & 4u) return SPIHT_ERR_CAPACITY;
+    if (e & 1u) return SPIHT_ERR_INTERNAL;
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// list coder plumbing
+// ------------------------------------------------------------------------------------------------
+
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// carve per-slot list scratch out of ctx->lists; returns pointers
+struct ListPtrs {
+    uint32_t *lip0, *lip1, *lsp, *lis0, *lis1, *lis2;
+    int32_t *lsp_val;
+};
+
+static int alloc_lists(spiht_ctx *ctx, const ListCaps &caps, int want_slots, bool decoder, int *nslots, ListPtrs *p) {
+    size_t per_slot = ((size_t)caps.lip * 2 + (size_t)caps.lsp * (decoder ? 2 : 1) + (size_t)caps.lis * 3) * 4;
+    // keep the scratch under ~24 GiB
+    const size_t budget = (size_t)24 << 30;
+    int slots = want_slots;
+    if ((size_t)slots * per_slot > budget) slots = (int)std::max<size_t>(1, budget / per_slot);
+    size_t s_lip = align256((size_t)caps.lip * 4 * slots), s_lsp = align256((size_t)caps.lsp * 4 * slots),
+           s_lis = align256((size_t)caps.lis * 4 * slots);
+    size_t total = 2 * s_lip + (decoder ? 2 : 1) * s_lsp + 3 * s_lis;
+    CHK(ensure(ctx, ctx->lists, total));
+    char *base = (char *)ctx->lists.p;
+    p->lip0 = (uint32_t *)base; base += s_lip;
+    p->lip1 = (uint32_t *)base; base += s_lip;
+    p->lsp = (uint32_t *)base; base += s_lsp;
+    p->lsp_val = nullptr;
+    if (decoder) { p->lsp_val = (int32_t *)base; base += s_lsp; }
+    p->lis0 = (uint32_t *)base; base += s_lis;
+    p->lis1 = (uint32_t *)base; base += s_lis;
+    p->lis2 = (uint32_t *)base; base += s_lis;
+    *nslots = slots;
+    return SPIHT_OK;
+}
+
+// Encode B device-resident coefficient arrays.  max_bits already validated; queues work on ctx->stream.
+static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int B, uint64_t max_bits_in, uint8_t *d_out,
+                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn) {
+    if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
+    if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
+    const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;  // encoder_decoder.rs:196
+    CHK(ensure(ctx, ctx->dmsb, (size_t)B * g.n));
+    CHK(ensure(ctx, ctx->lmsb, (size_t)B * g.n));
+    CHK(ensure(ctx, ctx->maxabs, (size_t)B * 4));
+    ListCaps caps;
+    list_caps(g, std::min<uint64_t>(max_bits, slot_stride * 8), &caps, nullptr);
+    int nslots = 0;
+    ListPtrs lp;
+    CHK(alloc_lists(ctx, caps, std::min(B, ctx->num_cu), false, &nslots, &lp));
+    {
+        StageTimer t(ctx, ST_MEMSET);
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * slot_stride, ctx->stream));
+    }
+    {
+        StageTimer t(ctx, ST_ABSMAX);
+        LAUNCHCHK(spiht_launch_absmax(d_x, B, g.n, (uint32_t *)ctx->maxabs.p, ctx->stream));
+    }
+    {
+        StageTimer t(ctx, ST_PYRAMID);
+        LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, ctx->stream));
+    }
+    EncArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = g;
+    a.caps = caps;
+    a.B = B;
+    a.nslots = nslots;
+    a.x = d_x;
+    a.dmsb = (const uint8_t *)ctx->dmsb.p;
+    a.lmsb = (const uint8_t *)ctx->lmsb.p;
+    a.maxabs = (const uint32_t *)ctx->maxabs.p;
+    a.max_bits = max_bits;
+    a.out = d_out;
+    a.slot_stride = slot_stride;
+    a.out_nbits = d_nbits;
+    a.out_maxn = d_maxn;
+    a.lip0 = lp.lip0; a.lip1 = lp.lip1; a.lsp = lp.lsp; a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
+    a.err = (uint32_t *)ctx->err.p;
+    memcpy(a.log2_thresh, ctx->log2_thresh, sizeof(a.log2_thresh));
+    {
+        StageTimer t(ctx, ST_ENC_LISTS);
+        LAUNCHCHK(spiht_launch_encode(&a, ctx->stream));
+    }
+    return SPIHT_OK;
+}
+
+static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, uint64_t slot_stride,
+                         const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out) {
+    if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
+    if (slot_stride * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
+    ListCaps caps;
+    list_caps(g, slot_stride * 8, &caps, nullptr);
+    int nslots = 0;
+    ListPtrs lp;
+    CHK(alloc_lists(ctx, caps, std::min(B, ctx->num_cu * 8), true, &nslots, &lp));
+    {
+        StageTimer t(ctx, ST_MEMSET);
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * g.n * 4, ctx->stream));
+    }
+    DecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = g;
+    a.caps = caps;
+    a.B = B;
+    a.nslots = nslots;
+    a.data = d_data;
+    a.slot_stride = slot_stride;
+    a.nbytes = d_nbytes;
+    a.max_n = d_maxn;
+    a.out = d_out;
+    a.lip0 = lp.lip0; a.lip1 = lp.lip1; a.lsp_idx = lp.lsp; a.lsp_val = lp.lsp_val;
+    a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
+    a.err = (uint32_t *)ctx->err.p;
+    {
+        StageTimer t(ctx, ST_DEC_LISTS);
+        LAUNCHCHK(spiht_launch_decode(&a, ctx->stream));
+    }
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// L2 boundary, single image, host buffers
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int spiht_encode_bound(int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, uint32_t max_abs,
+                                  uint64_t max_bits, uint64_t *bound_bytes) {
+    if (!bound_bytes) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    uint64_t bits = bound_bits(g, max_abs);
+    if (max_bits != 0) bits = std::min(bits, max_bits);
+    *bound_bytes = ((bits + 7) / 8 + 3) & ~3ull;
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_encode_i32(spiht_ctx *ctx, const int32_t *x, int64_t c, int64_t h, int64_t w, int64_t stride_c,
+                                int64_t stride_h, int64_t stride_w, int64_t ll_h, int64_t ll_w, uint64_t max_bits,
+                                uint8_t *out, uint64_t out_cap, uint64_t *out_nbits, uint8_t *max_n) {
+    if (!ctx || !out_nbits || !max_n || (!out && out_cap)) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (!x) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    // gather the strided view into a contiguous staging buffer (lib.rs:27 takes any strides)
+    std::vector<int32_t> stage;
+    const int32_t *src = x;
+    uint32_t max_abs = 0;
+    const bool contiguous = stride_w == 1 && stride_h == w && stride_c == h * w;
+    if (!contiguous) {
+        stage.resize(g.n);
+        size_t t = 0;
+        for (int64_t k = 0; k < c; k++)
+            for (int64_t i = 0; i < h; i++) {
+                const int32_t *row = x + k * stride_c + i * stride_h;
+                for (int64_t j = 0; j < w; j++) stage[t++] = row[j * stride_w];
+            }
+        src = stage.data();
+    }
+    for (size_t t = 0; t < g.n; t++) {
+        int32_t v = src[t];
+        uint32_t m = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+        if (m > max_abs) max_abs = m;
+    }
+    if (max_abs >= (1u << 30)) return SPIHT_ERR_MAGNITUDE;
+    uint64_t bits = bound_bits(g, max_abs);
+    if (max_bits != 0) bits = std::min(bits, max_bits);
+    if (bits >= 0xFFFFFF00ull * 8ull) return SPIHT_ERR_TOO_LARGE;
+    const uint64_t slot = std::max<uint64_t>(4, ((bits + 7) / 8 + 3) & ~3ull);
+    CHK(ensure(ctx, ctx->x, (size_t)g.n * 4));
+    CHK(ensure(ctx, ctx->out, slot));
+    CHK(ensure(ctx, ctx->nbits, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemcpyAsync(ctx->x.p, src, (size_t)g.n * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CHK(encode_device(ctx, g, (const int32_t *)ctx->x.p, 1, max_bits, (uint8_t *)ctx->out.p, slot,
+                      (uint64_t *)ctx->nbits.p, (uint8_t *)ctx->maxn.p));
+    uint64_t nbits = 0;
+    uint8_t mn = 0;
+    HIPCHK(hipMemcpyAsync(&nbits, ctx->nbits.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&mn, ctx->maxn.p, 1, hipMemcpyDeviceToHost, ctx->stream));
+    CHK(read_err(ctx));
+    *out_nbits = nbits;
+    *max_n = mn;
+    const uint64_t nbytes = (nbits + 7) / 8;
+    if (nbytes > out_cap) return SPIHT_ERR_CAPACITY;
+    if (nbytes) {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(out, ctx->out.p, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_decode_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
+                                int64_t w, int64_t ll_h, int64_t ll_w, int32_t *out) {
+    if (!ctx || !out || (!data && nbytes)) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (n > 30) return SPIHT_ERR_MAGNITUDE;
+    if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
+    CHK(ensure(ctx, ctx->data, slot));
+    CHK(ensure(ctx, ctx->nbytes, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(ensure(ctx, ctx->rec, (size_t)g.n * 4));
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemsetAsync(ctx->data.p, 0, slot, ctx->stream));
+        if (nbytes) HIPCHK(hipMemcpyAsync(ctx->data.p, data, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->nbytes.p, &nbytes, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->maxn.p, &n, 1, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // &nbytes / &n are stack temporaries
+    }
+    CHK(decode_device(ctx, g, (const uint8_t *)ctx->data.p, slot, (const uint64_t *)ctx->nbytes.p,
+                      (const uint8_t *)ctx->maxn.p, 1, (int32_t *)ctx->rec.p));
+    CHK(read_err(ctx));
+    {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(out, ctx->rec.p, (size_t)g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched, device-resident
+// ------------------------------------------------------------------------------------------------
+
+static int batch_chunk(const Geom &g) { return (int)std::max<int64_t>(1, 65535 / g.c); }
+
+extern "C" int spiht_encode_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
+                                      int64_t ll_h, int64_t ll_w, uint64_t max_bits, uint8_t *d_out,
+                                      uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n) {
+    if (!ctx || !d_x || !d_out || !d_nbits || !d_max_n || B < 0) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(clear_err(ctx));
+    const int chunk = batch_chunk(g);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        CHK(encode_device(ctx, g, d_x + (size_t)b0 * g.n, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride,
+                          d_nbits + b0, d_max_n + b0));
+    }
+    return read_err(ctx);
+}
+
+extern "C" int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
+                                      const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h,
+                                      int64_t w, int64_t ll_h, int64_t ll_w, int32_t *d_out) {
+    if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_out || B < 0) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(clear_err(ctx));
+    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out));
+    return read_err(ctx);
+}
+
+extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
+                                       int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb,
+                                       uint32_t *d_maxabs) {
+    if (!ctx || !d_x || !d_dmsb || !d_lmsb || !d_maxabs || B < 0) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (B == 0) return SPIHT_OK;
+    if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    {
+        StageTimer t(ctx, ST_ABSMAX);
+        LAUNCHCHK(spiht_launch_absmax(d_x, (int)B, g.n, d_maxabs, ctx->stream));
+    }
+    {
+        StageTimer t(ctx, ST_PYRAMID);
+        LAUNCHCHK(spiht_launch_pyramid(&g, (int)B, d_x, d_dmsb, d_lmsb, ctx->stream));
+    }
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image path
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int spiht_wavelet_id(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < SPIHT_NWAVELETS; i++)
+        if (!strcmp(SPIHT_WAVELETS[i].name, name)) return i;
+    if (!strcmp(name, "db1")) return spiht_wavelet_id("haar");
+    return -1;
+}
+extern "C" int spiht_mode_id(const char *name) {
+    if (!name) return -1;
+    static const char *names[] = {"reflect", "symmetric", "periodic", "zero", "constant"};
+    for (int i = 0; i < 5; i++)
+        if (!strcmp(names[i], name)) return i;
+    return -1;
+}
+
+extern "C" int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h,
+                              int64_t *ll_w, int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W) {
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS) return SPIHT_ERR_ARG;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    if (level_used) *level_used = ig.L;
+    if (ll_h) *ll_h = ig.ll_h;
+    if (ll_w) *ll_w = ig.ll_w;
+    if (enc_h) *enc_h = ig.enc_h;
+    if (enc_w) *enc_w = ig.enc_w;
+    if (rec_H) *rec_H = ig.rec_H;
+    if (rec_W) *rec_W = ig.rec_W;
+    return SPIHT_OK;
+}
+
+static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, const double **d_mults) {
+    *d_mults = nullptr;
+    if (!channel_mults) return SPIHT_OK;
+    CHK(ensure(ctx, ctx->mults, (size_t)c * 8));
+    HIPCHK(hipMemcpyAsync(ctx->mults.p, channel_mults, (size_t)c * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // caller's array may be a temporary
+    *d_mults = (const double *)ctx->mults.p;
+    return SPIHT_OK;
+}
+
+// pixels [planes,H,W] -> quantised packed array [planes,enc_h,enc_w]
+static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
+                       double q, const double *d_mults, int32_t *d_coeffs) {
+    const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
+    const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
+    if (ig.L == 0) {
+        StageTimer t(ctx, ST_DWT_REST);
+        LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, ctx->stream));
+        return SPIHT_OK;
+    }
+    {
+        // zero padding cells of coeffs_to_array
+        StageTimer t(ctx, ST_MEMSET);
+        HIPCHK(hipMemsetAsync(d_coeffs, 0, plane_out * planes * 4, ctx->stream));
+    }
+    if (ig.L >= 2) {
+        CHK(ensure(ctx, ctx->a0, (size_t)planes * ig.hs[1] * ig.ws[1] * 8));
+        if (ig.L >= 3) CHK(ensure(ctx, ctx->a1, (size_t)planes * ig.hs[2] * ig.ws[2] * 8));
+    }
+    const double *in = d_img;
+    for (int l = 1; l <= ig.L; l++) {
+        DwtKArgs a;
+        memset(&a, 0, sizeof(a));
+        a.c = c;
+        a.F = wv.F;
+        a.mode = mode;
+        a.in_h = (int32_t)ig.hs[l - 1]; a.in_w = (int32_t)ig.ws[l - 1];
+        a.out_h = (int32_t)ig.hs[l]; a.out_w = (int32_t)ig.ws[l];
+        a.off_h = (int32_t)ig.offh[l]; a.off_w = (int32_t)ig.offw[l];
+        a.enc_h = (int32_t)ig.enc_h; a.enc_w = (int32_t)ig.enc_w;
+        a.last = (l == ig.L) ? 1 : 0;
+        a.in = in;
+        a.ll_out = a.last ? nullptr : (double *)((l & 1) ? ctx->a0.p : ctx->a1.p);
+        a.coeffs = d_coeffs;
+        a.mults = d_mults;
+        a.q = q;
+        memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
+        memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
+        {
+            StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
+            LAUNCHCHK(spiht_launch_dwt_level(&a, planes, ctx->stream));
+        }
+        in = a.ll_out;
+    }
+    return SPIHT_OK;
+}
+
+// packed int32 array -> pixels [planes, rec_H, rec_W]
+static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, const ImgGeom &ig, int wavelet, double q,
+                       const double *d_mults, double *d_out) {
+    const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
+    const int F = wv.F;
+    if (ig.L == 0) {
+        StageTimer t(ctx, ST_IDWT_REST);
+        LAUNCHCHK(spiht_launch_dequant_plain(d_rec, d_out, (size_t)ig.enc_h * ig.enc_w, planes, c, d_mults, q, ctx->stream));
+        return SPIHT_OK;
+    }
+    // intermediate approximations ping-pong between a0/a1; sizes 2*band-F+2
+    size_t maxa = 0;
+    for (int l = ig.L; l >= 2; l--) maxa = std::max(maxa, (size_t)(2 * ig.hs[l] - F + 2) * (size_t)(2 * ig.ws[l] - F + 2));
+    if (maxa) {
+        CHK(ensure(ctx, ctx->a0, maxa * planes * 8));
+        CHK(ensure(ctx, ctx->a1, maxa * planes * 8));
+    }
+    const double *a_in = nullptr;
+    int64_t ah = ig.ll_h, aw = ig.ll_w;
+    for (int l = ig.L; l >= 1; l--) {
+        IdwtKArgs a;
+        memset(&a, 0, sizeof(a));
+        a.c = c;
+        a.F = F;
+        a.band_h = (int32_t)ig.hs[l]; a.band_w = (int32_t)ig.ws[l];
+        a.out_h = (int32_t)(2 * ig.hs[l] - F + 2); a.out_w = (int32_t)(2 * ig.ws[l] - F + 2);
+        a.a_h = (int32_t)ah; a.a_w = (int32_t)aw;
+        // waverec2 trim rule: the running approximation may be exactly one longer than the band
+        if (!((ah == ig.hs[l] || ah == ig.hs[l] + 1) && (aw == ig.ws[l] || aw == ig.ws[l] + 1))) return SPIHT_ERR_ARG;
+        a.off_h = (int32_t)ig.offh[l]; a.off_w = (int32_t)ig.offw[l];
+        a.enc_h = (int32_t)ig.enc_h; a.enc_w = (int32_t)ig.enc_w;
+        a.first = (l == ig.L) ? 1 : 0;
+        a.a_in = a_in;
+        a.rec = d_rec;
+        a.out = (l == 1) ? d_out : (double *)((l & 1) ? ctx->a1.p : ctx->a0.p);
+        a.mults = d_mults;
+        a.q = q;
+        memcpy(a.lo, wv.rec_lo, sizeof(double) * F);
+        memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
+        {
+            StageTimer t(ctx, l == 1 ? ST_IDWT_L1 : ST_IDWT_REST);
+            LAUNCHCHK(spiht_launch_idwt_level(&a, planes, ctx->stream));
+        }
+        a_in = a.out;
+        ah = a.out_h;
+        aw = a.out_w;
+    }
+    return SPIHT_OK;
+}
+
+static int check_img_args(int wavelet, int mode, int64_t B, int64_t c, int64_t H, int64_t W) {
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > 4) return SPIHT_ERR_ARG;
+    if (B < 0 || c < 1 || H < 1 || W < 1) return SPIHT_ERR_ARG;
+    if (H > (1 << 24) || W > (1 << 24)) return SPIHT_ERR_TOO_LARGE;
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_dwt_quant_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                         int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                         int32_t *d_coeffs) {
+    if (!ctx || !d_img || !d_coeffs) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int chunk = (int)std::max<int64_t>(1, 65535 / c);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults,
+                        d_coeffs + (size_t)b0 * c * ig.enc_h * ig.enc_w));
+    }
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H,
+                                            int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, double *d_img_out) {
+    if (!ctx || !d_rec || !d_img_out) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int chunk = (int)std::max<int64_t>(1, 65535 / c);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        CHK(dwt_inverse(ctx, d_rec + (size_t)b0 * c * ig.enc_h * ig.enc_w, nb * (int)c, (int)c, ig, wavelet, q_scale,
+                        d_mults, d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+    }
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H,
+                                            int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, uint64_t max_bits, uint8_t *d_out,
+                                            uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n,
+                                            int32_t *d_coeffs) {
+    if (!ctx || !d_img || !d_out || !d_nbits || !d_max_n) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    Geom g;
+    CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(clear_err(ctx));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int chunk = batch_chunk(g);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        int32_t *co = d_coeffs ? d_coeffs + (size_t)b0 * g.n : nullptr;
+        if (!co) {
+            CHK(ensure(ctx, ctx->coeffs, (size_t)nb * g.n * 4));
+            co = (int32_t *)ctx->coeffs.p;
+        }
+        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co));
+        CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
+                          d_max_n + b0));
+    }
+    return read_err(ctx);
+}
+
+extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
+                                            const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c,
+                                            int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, double *d_img_out, int32_t *d_rec) {
+    if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_img_out) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    Geom g;
+    CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(clear_err(ctx));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int chunk = batch_chunk(g);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        int32_t *rec = d_rec ? d_rec + (size_t)b0 * g.n : nullptr;
+        if (!rec) {
+            CHK(ensure(ctx, ctx->rec, (size_t)nb * g.n * 4));
+            rec = (int32_t *)ctx->rec.p;
+        }
+        CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec));
+        CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
+                        d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+    }
+    return read_err(ctx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// device memory helpers
+// ------------------------------------------------------------------------------------------------
+extern "C" int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 4);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return SPIHT_ERR_NOMEM;
+    }
+    return SPIHT_OK;
+}
+extern "C" int spiht_dev_free(spiht_ctx *ctx, void *d_ptr) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_ptr));
+    return SPIHT_OK;
+}
+extern "C" int spiht_dev_upload(spiht_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes) {
+    if (!ctx || (!d_dst && bytes) || (!h_src && bytes)) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+extern "C" int spiht_dev_download(spiht_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx || (!h_dst && bytes) || (!d_src && bytes)) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+extern "C" int spiht_dev_memset(spiht_ctx *ctx, void *d_dst, int value, uint64_t bytes) {
+    if (!ctx || (!d_dst && bytes)) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+    return SPIHT_OK;
+}

@@ -1,0 +1,128 @@
+// Shared host/device definitions for libspiht_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPIHT_MAX_LEVELS 32
+#define SPIHT_MAX_TAPS 20
+
+// Exact unsigned division by an invariant divisor d >= 2 (Granlund-Montgomery round-up form):
+//   q = (t + ((n - t) >> 1)) >> sh,  t = mulhi(m, n)
+struct FastDiv {
+    uint32_t m, sh, d, pad;
+};
+
+static inline FastDiv fastdiv_make(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    f.pad = 0;
+    if (d < 2) { f.m = 0; f.sh = 0; return f; }  // callers never divide by < 2
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;  // ceil(log2 d)
+    uint64_t m = ((1ull << 32) * ((1ull << l) - d)) / d + 1;
+    f.m = (uint32_t)m;
+    f.sh = l - 1;
+    return f;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> 1)) >> f.sh;
+}
+#endif
+
+// Geometry of one coefficient array [c,h,w] with an ll_h x ll_w root block.
+struct Geom {
+    int32_t c, h, w, ll_h, ll_w;
+    uint32_t hw;  // h*w
+    uint32_t n;   // c*h*w  (< 2^31)
+    uint32_t pad;
+    FastDiv div_w, div_hw;
+};
+
+// List entry: bit 31 = type A (1) / type B (0) for LIS entries; low 31 bits = linear index k*hw + i*w + j.
+#define ENT_A 0x80000000u
+#define ENT_IDX 0x7FFFFFFFu
+
+// Per-slot scratch of the list coder.  A "slot" serves one image at a time.
+struct ListCaps {
+    uint32_t lip, lsp, lis;  // capacities in entries
+    uint32_t pad;
+};
+
+struct EncArgs {
+    Geom g;
+    ListCaps caps;
+    int32_t B;
+    int32_t nslots;
+    const int32_t *x;        // [B, n]
+    const uint8_t *dmsb;     // [B, n]
+    const uint8_t *lmsb;     // [B, n]
+    const uint32_t *maxabs;  // [B]
+    uint64_t max_bits;       // already mapped: 0 -> unlimited
+    uint8_t *out;            // [B, slot_stride]
+    uint64_t slot_stride;    // bytes, multiple of 4
+    uint64_t *out_nbits;     // [B]
+    uint8_t *out_maxn;       // [B]
+    // scratch, per slot
+    uint32_t *lip0, *lip1, *lsp, *lis0, *lis1, *lis2;
+    uint32_t *err;           // device error word
+    float log2_thresh[32];   // log2_thresh[k]: smallest float m < 2^k with (u8)log2f(m) == k (host libm), or 2^k
+};
+
+struct DecArgs {
+    Geom g;
+    ListCaps caps;
+    int32_t B;
+    int32_t nslots;
+    const uint8_t *data;      // [B, slot_stride]
+    uint64_t slot_stride;     // bytes, multiple of 4
+    const uint64_t *nbytes;   // [B]
+    const uint8_t *max_n;     // [B]
+    int32_t *out;             // [B, n], zero-filled before launch
+    uint32_t *lip0, *lip1, *lsp_idx, *lis0, *lis1, *lis2;
+    int32_t *lsp_val;
+    uint32_t *err;
+};
+
+struct PyrArgs {
+    Geom g;
+    int32_t B;
+    int32_t round;            // 1..: index-doubling depth handled by this launch
+    const int32_t *x;
+    uint8_t *dmsb, *lmsb;
+    uint32_t *maxabs;
+};
+
+// One forward DWT level (dwt.hip)
+struct DwtKArgs {
+    int32_t c;             // channels (plane index = b*c + k)
+    int32_t F, mode;
+    int32_t in_h, in_w, out_h, out_w;
+    int32_t off_h, off_w, enc_h, enc_w;
+    int32_t last;          // coarsest level: LL is quantised into the packed array too
+    const double *in;      // [planes, in_h, in_w]
+    double *ll_out;        // [planes, out_h, out_w]
+    int32_t *coeffs;       // [planes, enc_h, enc_w]
+    const double *mults;   // device [c] or null
+    double q;
+    double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // dec_lo, dec_hi
+};
+
+// One inverse DWT level (dwt.hip)
+struct IdwtKArgs {
+    int32_t c;
+    int32_t F;
+    int32_t band_h, band_w;    // detail band size (= approximation size used)
+    int32_t out_h, out_w;      // 2*band - F + 2
+    int32_t a_h, a_w;          // stored size of the incoming approximation (>= band; trim rule)
+    int32_t off_h, off_w, enc_h, enc_w;
+    int32_t first;             // coarsest level: approximation comes from rec[0:band_h, 0:band_w]
+    const double *a_in;        // [planes, a_h, a_w]
+    const int32_t *rec;        // [planes, enc_h, enc_w]
+    double *out;               // [planes, out_h, out_w]
+    const double *mults;
+    double q;
+    double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // rec_lo, rec_hi
+};

@@ -1,0 +1,493 @@
+// SPIHT list decoder (gfx950): one wavefront owns one image at a time.
+//
+// Reproduces /root/reference/src/encoder_decoder.rs:307-454 on all 8*nbytes bits of the stream
+// (src/lib.rs:38 hands the pad bits to the decoder as data).  Unlike the encoder, the position of a
+// list entry's bits depends on every bit decoded before it, so the three passes are attacked
+// differently:
+//   * LIP pass: tokens are '0' | '1 s'.  For a 64-bit window the token-start mask is computed in O(1)
+//     with the carry trick used for escaped characters in SIMD JSON parsers (runs of ones pair up from
+//     their first bit); lane l then owns stream position l, its token rank is a popcount, and LIP
+//     reads / LSP+LIP writes are coalesced.
+//   * LIS pass: per generation, windows of 64 entries.  Unfired entries and fired B entries take one
+//     bit; only a fired A entry (1 + 4..8 bits) shifts what follows.  Lane l precomputes the length a
+//     fired A entry would have at stream position l; a scalar walk then hops from fired A to fired A
+//     (find-first-set on `bits & type-mask`), assigning every entry its position.  Outputs (next
+//     generation, retained list, LIP/LSP appends) are then produced in parallel with one packed
+//     wave scan.
+//   * refinement: bit t belongs to LSP entry t.
+// Decoded magnitudes live next to the LSP (lsp_val) and are scattered into the coefficient array
+// at the end; the few operations that consumed one of the last 8 bits of the stream (possible pad
+// bits, Q9) are replayed serially in list order so duplicated tree nodes (Q4) end exactly as the
+// reference's sequential writes leave them.
+#include "common.h"
+
+#define DEC_CH 2048  // 32-bit words of stream staged in LDS per wave
+#define DEC_TAIL 16
+#define POS_INVALID 0xFFFFFFFFu
+
+struct TailOp {
+    uint32_t idx;
+    int32_t val;   // value for a write, bit for a refine
+    uint32_t n;    // plane
+    uint32_t kind; // 0 = write, 1 = refine
+};
+
+struct DecShared {
+    uint32_t w[DEC_CH + 8];
+    TailOp tail[DEC_TAIL];
+};
+
+__device__ __forceinline__ uint64_t lt_mask(uint32_t lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+
+__device__ __forceinline__ uint64_t uni64(uint64_t v) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_up((int)lo, o);
+    hi = (uint32_t)__shfl_up((int)hi, o);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_exscan(uint64_t v, uint64_t &total, uint32_t lane) {
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = shfl_up_u64(inc, o);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)inc, 63);
+    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(inc >> 32), 63);
+    total = ((uint64_t)hi << 32) | lo;
+    return inc - v;
+}
+
+// encoder_decoder.rs:14-29
+__device__ __forceinline__ int32_t set_bit_i32(int32_t x, uint32_t n, uint32_t bit) {
+    uint32_t m = 1u << n;
+    if (x >= 0) return bit ? (int32_t)((uint32_t)x | m) : (int32_t)((uint32_t)x & ~m);
+    uint32_t a = (uint32_t)(-x);
+    a = bit ? (a | m) : (a & ~m);
+    return -(int32_t)a;
+}
+
+__device__ __forceinline__ void decomp(const Geom &g, uint32_t idx, uint32_t &k, uint32_t &i, uint32_t &j) {
+    k = fdiv(idx, g.div_hw);
+    uint32_t r = idx - k * g.hw;
+    i = fdiv(r, g.div_w);
+    j = r - i * (uint32_t)g.w;
+}
+
+__device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32_t i, uint32_t j) {
+    uint32_t r, cc;
+    if (i < (uint32_t)g.ll_h && j < (uint32_t)g.ll_w) {
+        r = (i & 1u) * (uint32_t)g.ll_h + (i & ~1u);
+        cc = (j & 1u) * (uint32_t)g.ll_w + (j & ~1u);
+    } else {
+        r = 2 * i;
+        cc = 2 * j;
+    }
+    return k * g.hw + r * (uint32_t)g.w + cc;
+}
+
+struct BitSrc {
+    const uint32_t *gw;   // stream words of this image
+    uint32_t nwords;      // words readable in the slot
+    uint32_t nbits;       // valid bits (8*nbytes)
+    uint32_t cb;          // first word staged in LDS
+};
+
+// stage words [wbase, wbase+DEC_CH+8) with everything at or past nbits forced to zero
+__device__ __forceinline__ void refill(DecShared &sh, BitSrc &bs, uint32_t wbase, uint32_t lane) {
+    __syncthreads();
+    bs.cb = wbase;
+    for (uint32_t t = lane; t < DEC_CH + 8; t += 64) {
+        uint32_t wi = wbase + t;
+        uint32_t v = 0;
+        uint64_t b0 = (uint64_t)wi * 32;
+        if (wi < bs.nwords && b0 < bs.nbits) {
+            v = bs.gw[wi];
+            uint32_t rem = bs.nbits - (uint32_t)b0;
+            if (rem < 32) v &= (1u << rem) - 1u;
+        }
+        sh.w[t] = v;
+    }
+    __syncthreads();
+}
+
+// make sure bits [P, P+need) (+64 of slack for peek64) are staged; P never decreases
+__device__ __forceinline__ void ensure(DecShared &sh, BitSrc &bs, uint32_t P, uint32_t need, uint32_t lane) {
+    uint32_t lastw = (uint32_t)(((uint64_t)P + need + 63) >> 5) + 2;
+    if (lastw >= bs.cb + DEC_CH + 8 || (P >> 5) < bs.cb) refill(sh, bs, P >> 5, lane);
+}
+
+__device__ __forceinline__ uint64_t peek64(const DecShared &sh, const BitSrc &bs, uint32_t pos) {
+    uint32_t w = (pos >> 5) - bs.cb, s = pos & 31;
+    uint64_t lo = (uint64_t)sh.w[w] | ((uint64_t)sh.w[w + 1] << 32);
+    uint32_t hi = sh.w[w + 2];
+    return s ? ((lo >> s) | ((uint64_t)hi << (64 - s))) : lo;
+}
+
+// Token-start mask of a LIP-pass window.  cin: bit 0 is the pending sign bit of the previous window's
+// last token.  cout: the token starting at bit 63 is '1' and its sign bit is the next window's bit 0.
+__device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t cin, uint32_t &cout) {
+    const uint64_t E = 0x5555555555555555ull, O = 0xAAAAAAAAAAAAAAAAull;
+    uint64_t Wc = cin ? (W & ~1ull) : W;
+    uint64_t RS = Wc & ~(Wc << 1);               // first bit of every run of ones
+    uint64_t ce = Wc + (RS & E);                 // carry ripples through runs starting on even bits
+    uint64_t co = Wc + (RS & O);
+    uint64_t Me = (ce ^ Wc) & Wc;                // bits of runs that start on an even position
+    uint64_t Mo = Wc & ~Me;
+    uint64_t G = (Me & O) | (Mo & E);            // odd offsets inside a run: sign bits
+    G |= ((ce & ~Wc) & O) | ((co & ~Wc) & E);    // the zero right after an odd-length run: sign bit
+    if (cin) G |= 1ull;
+    uint64_t S = ~G;
+    cout = (uint32_t)((S >> 63) & (W >> 63) & 1ull);
+    return S;
+}
+
+__global__ __launch_bounds__(64) void k_decode(DecArgs a) {
+    __shared__ DecShared sh;
+    const Geom g = a.g;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
+    const uint64_t ltm = lt_mask(lane);
+
+    uint32_t *lipA = a.lip0 + (size_t)slot * a.caps.lip;
+    uint32_t *lipB = a.lip1 + (size_t)slot * a.caps.lip;
+    uint32_t *lsp_idx = a.lsp_idx + (size_t)slot * a.caps.lsp;
+    int32_t *lsp_val = a.lsp_val + (size_t)slot * a.caps.lsp;
+    uint32_t *q0 = a.lis0 + (size_t)slot * a.caps.lis;
+    uint32_t *q1 = a.lis1 + (size_t)slot * a.caps.lis;
+    uint32_t *q2 = a.lis2 + (size_t)slot * a.caps.lis;
+
+    for (int b = (int)blockIdx.x; b < a.B; b += (int)gridDim.x) {
+        int32_t *__restrict__ out = a.out + (size_t)b * g.n;
+        BitSrc bs;
+        bs.gw = reinterpret_cast<const uint32_t *>(a.data + (size_t)b * a.slot_stride);
+        bs.nwords = (uint32_t)(a.slot_stride >> 2);
+        uint64_t nby = a.nbytes[b];
+        bool bad = false;
+        if (nby * 8 >= 0xFFFFFF00ull) { bad = true; nby = 0; }
+        if (nby > a.slot_stride) { bad = true; nby = 0; }
+        bs.nbits = (uint32_t)(nby * 8);
+        const uint32_t nbits = bs.nbits;
+        const uint32_t tail_start = nbits >= 8 ? nbits - 8 : 0;
+        int n = (int)a.max_n[b];
+        if (n > 30) { bad = true; n = 0; }
+        refill(sh, bs, 0, lane);
+
+        uint32_t *lip = lipA, *lipn = lipB;
+        uint32_t *lis = q0, *qa = q1, *qb = q2;
+        uint32_t lip_len = 0, lsp_len = 0, lis_len = 0;
+        uint32_t P = 0, cut = 0, ntail = 0;
+
+        // ---- initial LIP / LIS (encoder_decoder.rs:327-348) ----
+        const uint32_t nroot = (uint32_t)(g.ll_h * g.ll_w * g.c);
+        for (uint32_t base = 0; base < nroot; base += 64) {
+            uint32_t t = base + lane;
+            bool act = t < nroot;
+            uint32_t k = 0, i = 0, j = 0;
+            if (act) {
+                uint32_t ij = t / (uint32_t)g.c;
+                k = t - ij * (uint32_t)g.c;
+                i = ij / (uint32_t)g.ll_w;
+                j = ij - i * (uint32_t)g.ll_w;
+            }
+            uint32_t idx = k * g.hw + i * W + j;
+            bool inlis = act && (((i | j) & 1u) != 0);
+            uint64_t m = __ballot(inlis);
+            if (act && t < a.caps.lip) lip[t] = idx;
+            uint32_t o = lis_len + (uint32_t)__popcll(m & ltm);
+            if (inlis && o < a.caps.lis) lis[o] = idx | ENT_A;
+            lis_len += (uint32_t)__popcll(m);
+        }
+        lip_len = nroot;
+        if (lip_len > a.caps.lip || lis_len > a.caps.lis) bad = true;
+
+        bool done = bad;
+        for (; !done; --n) {
+            const uint32_t lsp_len0 = lsp_len;
+            const int32_t base_val = (n == 0) ? 1 : (int32_t)((1u << (n - 1)) + (1u << n));  // :364-370
+
+            // ---------------- LIP pass (encoder_decoder.rs:355-377) ----------------
+            {
+                uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0;
+                while (m_rem > 0 && !done) {
+                    if (P >= nbits) { done = true; break; }
+                    ensure(sh, bs, P, 128, lane);
+                    const uint64_t Wd = uni64(peek64(sh, bs, P));
+                    const uint32_t nxtbit = uni32((uint32_t)(peek64(sh, bs, P + 64) & 1ull));
+                    const uint32_t vb = (nbits - P) < 64u ? (nbits - P) : 64u;
+                    uint32_t cout;
+                    uint64_t S = lip_starts(Wd, cin, cout);
+                    if (vb < 64) S &= (1ull << vb) - 1ull;
+                    const uint32_t cnt = (uint32_t)__popcll(S);
+                    const bool isS = (S >> lane) & 1ull;
+                    const uint32_t rank = (uint32_t)__popcll(S & ltm);
+                    const bool inpass = isS && rank < m_rem;
+                    const uint32_t sig = (uint32_t)(Wd >> lane) & 1u;
+                    const bool trunc = inpass && sig && (P + lane + 1 >= nbits);
+                    const bool valid = inpass && !trunc;
+                    const uint32_t sgn = lane < 63 ? ((uint32_t)(Wd >> (lane + 1)) & 1u) : nxtbit;
+                    const uint32_t e = valid ? lip[tok_base + rank] : 0u;
+                    const uint64_t sigm = __ballot(valid && sig);
+                    const uint64_t nsm = __ballot(valid && !sig);
+                    const uint32_t nsig = (uint32_t)__popcll(sigm);
+                    if (lsp_len + nsig > a.caps.lsp) { bad = true; done = true; break; }
+                    const bool istail = valid && sig && (P + lane + 1 >= tail_start);
+                    const uint64_t tm = __ballot(istail);
+                    if (valid && sig) {
+                        uint32_t t = lsp_len + (uint32_t)__popcll(sigm & ltm);
+                        int32_t v = sgn ? base_val : -base_val;
+                        lsp_idx[t] = e;
+                        lsp_val[t] = istail ? 0 : v;
+                        if (istail) {
+                            uint32_t tp = ntail + (uint32_t)__popcll(tm & ltm);
+                            if (tp < DEC_TAIL) { sh.tail[tp].idx = e; sh.tail[tp].val = v; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 0; }
+                        }
+                    } else if (valid) {
+                        lipn[lipn_len + (uint32_t)__popcll(nsm & ltm)] = e;
+                    }
+                    ntail += (uint32_t)__popcll(tm);
+                    lsp_len += nsig;
+                    lipn_len += (uint32_t)__popcll(nsm);
+                    if (__ballot(trunc)) { done = true; break; }
+                    if (cnt > m_rem) {
+                        // the pass ends inside this window, at the start of token number m_rem
+                        uint64_t pm = __ballot(isS && rank == m_rem);
+                        P += (uint32_t)__builtin_ctzll(pm);
+                        m_rem = 0;
+                        cin = 0;
+                    } else {
+                        m_rem -= cnt;
+                        tok_base += cnt;
+                        P += 64;
+                        cin = cout;
+                    }
+                }
+                if (cin) P += 1;
+                { uint32_t *t = lip; lip = lipn; lipn = t; }
+                lip_len = lipn_len;
+            }
+            if (done) break;
+
+            // ---------------- LIS pass (encoder_decoder.rs:379-436) ----------------
+            uint32_t *cur = lis, *nxt = qa, *ret = qb;
+            uint32_t cur_len = lis_len, ret_len = 0;
+            while (cur_len > 0 && !done) {
+                uint32_t nxt_len = 0;
+                for (uint32_t e0 = 0; e0 < cur_len && !done; e0 += 64) {
+                    const uint32_t nE = (cur_len - e0) < 64u ? (cur_len - e0) : 64u;
+                    const bool act = lane < nE;
+                    const uint32_t e = act ? cur[e0 + lane] : 0u;
+                    const uint32_t idx = e & ENT_IDX;
+                    const bool isA = (e & ENT_A) != 0;
+                    const uint64_t TA = __ballot(act && isA);
+                    uint32_t mypos = POS_INVALID;
+                    ensure(sh, bs, P, 64 * 9 + 192, lane);  // whole window span staged: no refill during the walk
+                    // ---- position walk (uniform control flow) ----
+                    uint32_t i = 0;
+                    while (i < nE) {
+                        if (P >= nbits) break;
+                        const uint64_t lo = uni64(peek64(sh, bs, P));
+                        const uint64_t hi = uni64(peek64(sh, bs, P + 64));
+                        // length of a fired type-A entry starting at window position `lane`
+                        uint32_t LAv;
+                        {
+                            uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
+                            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu;
+                            uint32_t ns = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                uint32_t s = pl & 1u;
+                                pl >>= 1 + s;
+                                ns += s;
+                            }
+                            LAv = 5 + ns;
+                        }
+                        const uint32_t vb = (nbits - P) < 64u ? (nbits - P) : 64u;
+                        uint32_t pos = 0;
+                        while (i < nE && pos < vb) {
+                            uint64_t cand = lo & ((TA >> i) << pos) & (~0ull << pos);
+                            const uint32_t lim = pos + (nE - i);
+                            if (lim < 64) cand &= (1ull << lim) - 1ull;
+                            if (cand == 0) {
+                                uint32_t z = (vb - pos) < (nE - i) ? (vb - pos) : (nE - i);
+                                if (lane >= i && lane < i + z) mypos = P + pos + (lane - i);
+                                i += z;
+                                pos += z;
+                            } else {
+                                const uint32_t f = (uint32_t)__builtin_ctzll(cand);
+                                const uint32_t z = f - pos;
+                                if (lane >= i && lane <= i + z) mypos = P + pos + (lane - i);
+                                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)LAv, (int)f);
+                                i += z + 1;
+                                pos = f + len;
+                            }
+                        }
+                        P += pos;
+                    }
+                    // ---- per-entry outputs ----
+                    const bool have = act && mypos != POS_INVALID && mypos < nbits;
+                    bool stop = act && !have;
+                    uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0, nT = 0;
+                    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0;
+                    bool fired = false;
+                    if (have) {
+                        const uint32_t avail = nbits - mypos;
+                        const uint32_t bits = (uint32_t)peek64(sh, bs, mypos) & 0xFFFFu;
+                        fired = bits & 1u;
+                        if (!fired) {
+                            nR = 1;
+                        } else {
+                            uint32_t k, ii, jj;
+                            decomp(g, idx, k, ii, jj);
+                            cb = child_base(g, k, ii, jj);
+                            if (!isA) {
+                                nQ = 4;
+                            } else {
+                                uint32_t o = 1;
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                    if (!stop) {
+                                        if (o >= avail) { stop = true; }
+                                        else if ((bits >> o) & 1u) {
+                                            if (o + 1 >= avail) { stop = true; }
+                                            else {
+                                                sigm |= 1u << q;
+                                                signm |= ((bits >> (o + 1)) & 1u) << q;
+                                                if (mypos + o + 1 >= tail_start) tailm |= 1u << q;
+                                                o += 2;
+                                            }
+                                        } else {
+                                            lipm |= 1u << q;
+                                            o += 1;
+                                        }
+                                    }
+                                }
+                                nLSP = (uint32_t)__popc(sigm);
+                                nLIP = (uint32_t)__popc(lipm);
+                                nT = (uint32_t)__popc(tailm);
+                                if (!stop) nQ = (4 * ii + 3 < H && 4 * jj + 3 < W) ? 1u : 0u;  // :411-414
+                            }
+                        }
+                    }
+                    uint64_t pk = (uint64_t)nQ | ((uint64_t)nR << 12) | ((uint64_t)nLIP << 24) | ((uint64_t)nLSP << 36) |
+                                  ((uint64_t)nT << 48);
+                    uint64_t tot;
+                    uint64_t ex = wave_exscan(pk, tot, lane);
+                    const uint32_t tQ = (uint32_t)tot & 0xfffu, tR = (uint32_t)(tot >> 12) & 0xfffu;
+                    const uint32_t tLIP = (uint32_t)(tot >> 24) & 0xfffu, tLSP = (uint32_t)(tot >> 36) & 0xfffu;
+                    const uint32_t tT = (uint32_t)(tot >> 48) & 0xfffu;
+                    if (nxt_len + tQ > a.caps.lis || ret_len + tR > a.caps.lis || lip_len + tLIP > a.caps.lip ||
+                        lsp_len + tLSP > a.caps.lsp) { bad = true; done = true; break; }
+                    if (have) {
+                        if (!fired) {
+                            ret[ret_len + ((uint32_t)(ex >> 12) & 0xfffu)] = e;
+                        } else if (!isA) {
+                            uint32_t oq = nxt_len + ((uint32_t)ex & 0xfffu);
+                            nxt[oq] = cb | ENT_A;
+                            nxt[oq + 1] = (cb + 1) | ENT_A;
+                            nxt[oq + 2] = (cb + W) | ENT_A;
+                            nxt[oq + 3] = (cb + W + 1) | ENT_A;
+                        } else {
+                            uint32_t ol = lip_len + ((uint32_t)(ex >> 24) & 0xfffu);
+                            uint32_t os = lsp_len + ((uint32_t)(ex >> 36) & 0xfffu);
+                            uint32_t ot = ntail + ((uint32_t)(ex >> 48) & 0xfffu);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                uint32_t ci = cb + (q >> 1) * W + (q & 1);
+                                if (sigm & (1u << q)) {
+                                    int32_t v = ((signm >> q) & 1u) ? base_val : -base_val;
+                                    bool tl = (tailm >> q) & 1u;
+                                    lsp_idx[os] = ci;
+                                    lsp_val[os] = tl ? 0 : v;
+                                    os++;
+                                    if (tl) {
+                                        if (ot < DEC_TAIL) { sh.tail[ot].idx = ci; sh.tail[ot].val = v; sh.tail[ot].n = (uint32_t)n; sh.tail[ot].kind = 0; }
+                                        ot++;
+                                    }
+                                } else if (lipm & (1u << q)) {
+                                    lip[ol++] = ci;
+                                }
+                            }
+                            if (nQ) nxt[nxt_len + ((uint32_t)ex & 0xfffu)] = idx;  // type B
+                        }
+                    }
+                    nxt_len += tQ; ret_len += tR; lip_len += tLIP; lsp_len += tLSP; ntail += tT;
+                    if (__ballot(stop)) done = true;
+                }
+                __syncthreads();  // entries of the next generation are read by other lanes
+                { uint32_t *t = cur; cur = nxt; nxt = t; }
+                cur_len = nxt_len;
+            }
+            if (done) break;
+            lis = ret; lis_len = ret_len;
+            qa = cur; qb = nxt;
+
+            // ---------------- refinement (encoder_decoder.rs:438-444) ----------------
+            {
+                const uint32_t left = nbits > P ? nbits - P : 0u;
+                const uint32_t count = lsp_len0 < left ? lsp_len0 : left;
+                for (uint32_t t0 = 0; t0 < count; t0 += 64) {
+                    ensure(sh, bs, P + t0, 64, lane);
+                    uint32_t t = t0 + lane;
+                    if (t < count) {
+                        uint32_t pos = P + t;
+                        uint32_t bit = (sh.w[(pos >> 5) - bs.cb] >> (pos & 31)) & 1u;
+                        bool tl = pos >= tail_start;
+                        if (!tl) lsp_val[t] = set_bit_i32(lsp_val[t], (uint32_t)n, bit);
+                        uint64_t tm = __ballot(tl);
+                        if (tl) {
+                            uint32_t tp = ntail + (uint32_t)__popcll(tm & ltm);
+                            if (tp < DEC_TAIL) { sh.tail[tp].idx = lsp_idx[t]; sh.tail[tp].val = (int32_t)bit; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 1; }
+                        }
+                        ntail += (uint32_t)__popcll(tm);
+                    }
+                    ntail = uni32(ntail);
+                }
+                P += count;
+                if (count < lsp_len0) { cut = count; done = true; }
+            }
+            if (n == 0) break;
+        }
+
+        // ---------------- scatter decoded values ----------------
+        __syncthreads();
+        for (uint32_t t = cut + lane; t < lsp_len; t += 64) {
+            int32_t v = lsp_val[t];
+            if (v) out[lsp_idx[t]] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        for (uint32_t t = lane; t < cut; t += 64) {
+            int32_t v = lsp_val[t];
+            if (v) out[lsp_idx[t]] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (lane == 0) {
+            uint32_t nt = ntail < DEC_TAIL ? ntail : DEC_TAIL;
+            for (uint32_t q = 0; q < nt; q++) {
+                TailOp op = sh.tail[q];
+                if (op.kind == 0) out[op.idx] = op.val;
+                else out[op.idx] = set_bit_i32(out[op.idx], op.n, (uint32_t)op.val);
+            }
+            if (bad || ntail > DEC_TAIL) atomicOr(a.err, 1u);
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int spiht_launch_decode(const DecArgs *a, hipStream_t st) {
+    int grid = a->nslots < a->B ? a->nslots : a->B;
+    if (grid < 1) return 0;
+    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(64), 0, st, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,166 @@
+// Significance pyramid for the SPIHT list coder (gfx950).
+//
+// Replaces the recursive significance search of the reference (is_set_sig / is_l_sig,
+// /root/reference/src/encoder_decoder.rs:78-121), which walks a whole sub-tree for every
+// insignificant LIS entry in every bit-plane.  Here the set maxima are computed once:
+//
+//   S(p) = max(|x_p|, D(p))          D(p) = max over offspring o of S(o)
+//   L(p) = max over offspring o that themselves have offspring of D(o)
+//
+// with offspring as get_offspring (encoder_decoder.rs:43-75): index doubling for every node
+// outside the ll_h x ll_w root block, the 2x2-block remap for root nodes.  Only the position of
+// the most significant bit matters ("D(p) >= 2^n"), so one byte per node is stored:
+// code = 0 for an all-zero/empty set, else 1 + floor(log2(max)).  "significant at plane n" is
+// code > n.
+//
+// A node (i,j) outside the root block has a sub-tree of depth >= d iff i*2^d+1 < h and
+// j*2^d+1 < w (its top-left descendant chain is the longest), so launch `round` d handles the
+// nodes of depth exactly d; their offspring were finished by earlier rounds.  Round 1 reads 3/4
+// of the array, coalesced; the rest is geometrically smaller.  HBM-bound: 4 B read per
+// coefficient, ~1/4 + 1/16 B written.
+#include "common.h"
+
+__device__ __forceinline__ uint32_t msb_code(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
+__device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 ? -x : x); }
+
+// max |x| per image (encoder_decoder.rs:165).  grid: (blocks, B)
+__global__ __launch_bounds__(256) void k_absmax(const int32_t *__restrict__ x, uint32_t n, uint32_t *__restrict__ maxabs) {
+    const int32_t *xi = x + (size_t)blockIdx.y * n;
+    uint32_t m = 0;
+    uint32_t n4 = n >> 2;
+    // 16-byte loads when the image base is 16-byte aligned (n multiple of 4 keeps every image aligned)
+    if ((n & 3u) == 0 && (reinterpret_cast<uintptr_t>(xi) & 15u) == 0) {
+        const int4 *x4 = reinterpret_cast<const int4 *>(xi);
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += gridDim.x * blockDim.x) {
+            int4 v = x4[t];
+            m = max(m, max(max(iabs_u(v.x), iabs_u(v.y)), max(iabs_u(v.z), iabs_u(v.w))));
+        }
+    } else {
+        for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x)
+            m = max(m, iabs_u(xi[t]));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    __shared__ uint32_t s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s[0], s[1]), max(s[2], s[3]));
+        if (m) atomicMax(&maxabs[blockIdx.y], m);
+    }
+}
+
+// One index-doubling round.  grid: (ceil(gj/64), ceil(gi/4), B*c), block (64,4).
+__global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a) {
+    const Geom g = a.g;
+    const int d = a.round;
+    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t i = blockIdx.y * 4 + threadIdx.y;
+    const uint32_t bk = blockIdx.z;  // b*c + k
+    const uint32_t h = (uint32_t)g.h, w = (uint32_t)g.w;
+    // depth >= d ?
+    if ((uint64_t)i * (1ull << d) + 1 >= h || (uint64_t)j * (1ull << d) + 1 >= w) return;
+    // depth >= d+1 -> a later round
+    if ((uint64_t)i * (2ull << d) + 1 < h && (uint64_t)j * (2ull << d) + 1 < w) return;
+    // root-block nodes use the remap rule (k_pyr_ll)
+    if (i < (uint32_t)g.ll_h && j < (uint32_t)g.ll_w) return;
+    const size_t base = (size_t)bk * g.hw;
+    const int32_t *x = a.x + base;
+    uint8_t *dm = a.dmsb + base;
+    uint8_t *lm = a.lmsb + base;
+    const uint32_t ci = 2 * i, cj = 2 * j;
+    const uint32_t c0 = ci * w + cj;
+    uint32_t dcode = 0, lcode = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t oi = ci + (q >> 1), oj = cj + (q & 1);
+        uint32_t o = c0 + (q >> 1) * w + (q & 1);
+        uint32_t s = msb_code(iabs_u(x[o]));
+        if (d > 1 && 2 * oi + 1 < h && 2 * oj + 1 < w) {
+            uint32_t dc = dm[o];
+            s = max(s, dc);
+            lcode = max(lcode, dc);
+        }
+        dcode = max(dcode, s);
+    }
+    dm[i * w + j] = (uint8_t)dcode;
+    lm[i * w + j] = (uint8_t)lcode;
+}
+
+// Root block (encoder_decoder.rs:44-63).  grid: (ceil(ll_w*ll_h/256), 1, B*c)
+__global__ __launch_bounds__(256) void k_pyr_ll(PyrArgs a) {
+    const Geom g = a.g;
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint32_t)(g.ll_h * g.ll_w)) return;
+    uint32_t i = t / (uint32_t)g.ll_w, j = t - i * (uint32_t)g.ll_w;
+    if (((i | j) & 1u) == 0) return;  // both even: no offspring
+    const uint32_t h = (uint32_t)g.h, w = (uint32_t)g.w;
+    const size_t base = (size_t)blockIdx.z * g.hw;
+    const int32_t *x = a.x + base;
+    uint8_t *dm = a.dmsb + base;
+    uint8_t *lm = a.lmsb + base;
+    uint32_t ri = (i & 1u) * (uint32_t)g.ll_h + (i & ~1u);
+    uint32_t rj = (j & 1u) * (uint32_t)g.ll_w + (j & ~1u);
+    uint32_t dcode = 0, lcode = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        uint32_t oi = ri + (q >> 1), oj = rj + (q & 1);
+        uint32_t o = oi * w + oj;
+        uint32_t s = msb_code(iabs_u(x[o]));
+        if (2 * oi + 1 < h && 2 * oj + 1 < w) {
+            uint32_t dc = dm[o];
+            s = max(s, dc);
+            lcode = max(lcode, dc);
+        }
+        dcode = max(dcode, s);
+    }
+    dm[i * w + j] = (uint8_t)dcode;
+    lm[i * w + j] = (uint8_t)lcode;
+}
+
+// ---- host launchers -------------------------------------------------------------------------
+
+extern "C" int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(d_maxabs, 0, sizeof(uint32_t) * (size_t)B, st);
+    if (e != hipSuccess) return (int)e;
+    uint32_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_absmax, dim3(blocks, B), dim3(256), 0, st, d_x, n, d_maxabs);
+    return (int)hipGetLastError();
+}
+
+// number of index-doubling rounds needed: max depth of a node outside the root block
+extern "C" int spiht_pyr_rounds(const Geom *g) {
+    int best = 0;
+    // the deepest non-root nodes are (0, ll_w) and (ll_h, 0)
+    for (int d = 1; d < 31; d++) {
+        bool a = ((uint64_t)g->ll_w << d) + 1 < (uint64_t)g->w;   // node (0, ll_w): i = 0 always passes
+        bool b = ((uint64_t)g->ll_h << d) + 1 < (uint64_t)g->h;   // node (ll_h, 0)
+        if (a || b) best = d; else break;
+    }
+    return best;
+}
+
+extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb,
+                                    hipStream_t st) {
+    PyrArgs a;
+    a.g = *g;
+    a.B = B;
+    a.x = d_x;
+    a.dmsb = d_dmsb;
+    a.lmsb = d_lmsb;
+    a.maxabs = nullptr;
+    int rounds = spiht_pyr_rounds(g);
+    for (int d = 1; d <= rounds; d++) {
+        a.round = d;
+        uint32_t gi = (uint32_t)(((uint64_t)g->h - 1 + (1ull << d) - 1) >> d);
+        uint32_t gj = (uint32_t)(((uint64_t)g->w - 1 + (1ull << d) - 1) >> d);
+        if (gi == 0 || gj == 0) continue;
+        dim3 grid((gj + 63) / 64, (gi + 3) / 4, (uint32_t)(B * g->c));
+        hipLaunchKernelGGL(k_pyr_round, grid, dim3(64, 4), 0, st, a);
+    }
+    a.round = 0;
+    dim3 grid((uint32_t)((g->ll_h * g->ll_w + 255) / 256), 1, (uint32_t)(B * g->c));
+    hipLaunchKernelGGL(k_pyr_ll, grid, dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,234 @@
+"""Counterpart of the reference's public Python API (/root/reference/spiht/spiht_wrapper.py).
+
+Same names, defaults, field order and exceptions:
+    SpihtSettings, EncodingResult, ENCODER_DECODER_VERSION, encode_image, decode_image,
+    decode_rec_array, decode_from_rec_arr, get_slices_and_h_w, quantize, dequantize
+What differs is where the arithmetic runs: the multilevel DWT (pywt.wavedec2/waverec2 in the reference),
+the Mallat packing, the per-channel scaling, the quantisation and the SPIHT coder all execute as HIP kernels
+on the MI355X through libspiht_hip.so; the pixel array is uploaded once and only the bitstream comes back.
+"""
+import ctypes as C
+from dataclasses import asdict, dataclass
+from typing import Any, List, Optional, Tuple, Union
+
+import numpy as np
+
+from . import _lib, color_models
+from . import spiht as spiht_rs
+
+
+def quantize(arr, q_scale=10.):
+    """wrapper:9-11 (host helper kept for API parity; the hot path quantises inside the DWT kernel)"""
+    arr = arr * q_scale
+    return arr.astype(np.int32)
+
+
+def dequantize(arr, q_scale=10.):
+    """wrapper:13-14"""
+    return arr / q_scale
+
+
+ENCODER_DECODER_VERSION = "0.0.2"
+
+
+@dataclass
+class SpihtSettings:
+    """Parameters that are not particular to a single image (wrapper:20-63): field order is API
+    (demonstrate.py:23-29 passes them positionally)."""
+    wavelet: str = 'bior2.2'
+    quantization_scale: float = 50.0
+    mode: str = 'reflect'
+    color_model: Optional[str] = None
+    per_channel_quant_scales: Optional[List[float]] = None
+
+
+@dataclass
+class EncodingResult:
+    """wrapper:65-89.  h, w, c are IMAGE dims; level may be None."""
+    encoded_bytes: bytes
+    h: int
+    w: int
+    c: int
+    max_n: int
+    level: Optional[int]
+    _encoding_version: str = ENCODER_DECODER_VERSION
+
+    def to_dict(self):
+        return {f"encoding_result_{k}": v for k, v in asdict(self).items()}
+
+    @staticmethod
+    def from_dict(d):
+        d = {k.removeprefix('encoding_result_'): v for k, v in d.items() if k.startswith('encoding_result_')}
+        return EncodingResult(**d)
+
+
+def _wavelet_mode_ids(spiht_settings):
+    L = _lib.lib()
+    wid = L.spiht_wavelet_id(str(spiht_settings.wavelet).encode())
+    if wid < 0:
+        raise ValueError("Unknown wavelet name '%s', supported: bior2.2, bior4.4, bior6.8, haar" % spiht_settings.wavelet)
+    mid = L.spiht_mode_id(str(spiht_settings.mode).encode())
+    if mid < 0:
+        raise ValueError("Unknown mode name '%s', supported: reflect, symmetric, periodic, zero, constant"
+                         % spiht_settings.mode)
+    return wid, mid
+
+
+def _geometry(h, w, wid, level):
+    L = _lib.lib()
+    lv = C.c_int()
+    v = [C.c_int64() for _ in range(6)]
+    if level is not None and level < 0:
+        raise ValueError("Level value of %d is too low . Minimum level is 0." % level)
+    _lib.check(L.spiht_geometry(int(h), int(w), wid, -1 if level is None else int(level), C.byref(lv),
+                                *[C.byref(t) for t in v]))
+    return dict(level=lv.value, ll_h=v[0].value, ll_w=v[1].value, enc_h=v[2].value, enc_w=v[3].value,
+                rec_h=v[4].value, rec_w=v[5].value)
+
+
+_FILTER_LEN = {"bior2.2": 6, "bior4.4": 10, "bior6.8": 18, "haar": 2, "db1": 2}
+
+
+def get_slices_and_h_w(h: int, w: int, spiht_settings: SpihtSettings, level: Optional[int]):
+    """wrapper:92-139: the pywt.coeffs_to_array slices of a (1,h,w) wavedec2, the height and the width of the
+    packed coefficient array.  Closed form len' = (len + F - 1)//2 instead of pywt.wavedecn_shapes."""
+    wid, _ = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(h, w, wid, level)
+    F = _FILTER_LEN[spiht_settings.wavelet]
+    hs, ws = [h], [w]
+    for _ in range(g["level"]):
+        hs.append((hs[-1] + F - 1) // 2)
+        ws.append((ws[-1] + F - 1) // 2)
+    start_h, start_w = hs[-1], ws[-1]
+    slices: List[Any] = [(slice(None), slice(start_h), slice(start_w))]
+    for lv in range(g["level"], 0, -1):
+        dh, dw = hs[lv], ws[lv]
+        slices.append({
+            "ad": (slice(None), slice(0, dh), slice(start_w, start_w + dw)),
+            "da": (slice(None), slice(start_h, start_h + dh), slice(0, dw)),
+            "dd": (slice(None), slice(start_h, start_h + dh), slice(start_w, start_w + dw)),
+        })
+        start_h += dh
+        start_w += dw
+    return slices, start_h, start_w
+
+
+def _mults_arg(per_channel_quant_scales, c):
+    if per_channel_quant_scales is None:
+        return None, None
+    m = np.ascontiguousarray(np.array(per_channel_quant_scales), dtype=np.float64)
+    if m.ndim != 1 or m.shape[0] != c:
+        # numpy broadcasting of channel_mults[:,None,None] * coeffs_arr fails the same way (wrapper:167-170)
+        raise ValueError("operands could not be broadcast together with shapes (%d,1,1) (%d,...)" % (m.shape[0], c))
+    return m, C.c_void_p(m.ctypes.data)
+
+
+def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSettings(), level: Optional[int] = None,
+                 max_bits: Optional[int] = None):
+    """wrapper:142-189.  image: (C,H,W) floating point pixels.  Returns EncodingResult."""
+    if image.ndim != 3:
+        raise ValueError('image ndim must be 3: c,h,w')
+    c, h, w = image.shape
+
+    color_model = spiht_settings.color_model
+    if color_model is not None:
+        image = color_models.convert(image, 'RGB', color_model)
+
+    wid, mid = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(h, w, wid, level)
+    mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
+
+    if max_bits == None:  # noqa: E711  (as the reference)
+        max_bits = 99999999999999999
+    max_bits = spiht_rs._as_usize(max_bits, "max_bits")
+
+    ctx = _lib.default_context()
+    L = _lib.lib()
+    img = np.ascontiguousarray(image, dtype=np.float64)
+    bound = C.c_uint64()
+    _lib.check(L.spiht_encode_bound(c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], 0x3FFFFFFF, max_bits,
+                                    C.byref(bound)))
+    slot = max(int(bound.value), 4)
+    d_img = ctx.alloc(img.nbytes)
+    d_out = ctx.alloc(slot)
+    d_meta = ctx.alloc(16)
+    try:
+        ctx.upload(d_img, img)
+        _lib.check(L.spiht_encode_image_batch_f64(
+            ctx.handle, C.c_void_p(d_img), 1, c, h, w, wid, mid, -1 if level is None else int(level),
+            float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(d_out), slot,
+            C.c_void_p(d_meta), C.c_void_p(d_meta + 8), None))
+        meta = np.zeros(2, dtype=np.uint64)
+        ctx.download(meta, d_meta)
+        nbits = int(meta[0])
+        max_n = int(meta[1]) & 0xFF
+        nbytes = (nbits + 7) // 8
+        out = np.empty(nbytes, dtype=np.uint8)
+        if nbytes:
+            ctx.download(out, d_out)
+    finally:
+        ctx.free(d_img)
+        ctx.free(d_out)
+        ctx.free(d_meta)
+
+    return EncodingResult(out.tobytes(), h, w, c, max_n, level)
+
+
+def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
+                 return_metadata: bool = False) -> Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]:
+    """wrapper:192-216"""
+    d = decode_rec_array(encoding_result, spiht_settings, return_metadata)
+    spiht_metadata = d.pop("spiht_metadata", None)
+    image = decode_from_rec_arr(**d, spiht_settings=spiht_settings)
+    if return_metadata:
+        return image, spiht_metadata
+    return image
+
+
+def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSettings, return_metadata: bool = False):
+    """wrapper:218-257"""
+    encoded_bytes = encoding_result.encoded_bytes
+    h, w, c = encoding_result.h, encoding_result.w, encoding_result.c
+    max_n, level = encoding_result.max_n, encoding_result.level
+
+    if encoding_result._encoding_version != ENCODER_DECODER_VERSION:
+        raise ValueError(encoding_result._encoding_version)
+
+    slices, enc_h, enc_w = get_slices_and_h_w(h, w, spiht_settings, level)
+    ll_h, ll_w = slices[0][1].stop, slices[0][2].stop
+
+    if return_metadata:
+        raise NotImplementedError("return_metadata=True needs decode_with_metadata (SURVEY.md 8 f-1)")
+    rec_arr = spiht_rs.decode(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w)
+    return dict(rec_arr=rec_arr, slices=slices, spiht_metadata=None, h=h, w=w, level=level)
+
+
+def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settings: SpihtSettings, slices=None):
+    """wrapper:259-281: (rec / channel_mults) / q -> inverse DWT -> colour back.  Runs on the GPU."""
+    wid, mid = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(h, w, wid, level)
+    rec = np.ascontiguousarray(rec_arr, dtype=np.int32)
+    if rec.ndim != 3 or rec.shape[1] != g["enc_h"] or rec.shape[2] != g["enc_w"]:
+        raise ValueError("rec_arr shape %s does not match the coefficient array (c,%d,%d)"
+                         % (rec.shape, g["enc_h"], g["enc_w"]))
+    c = rec.shape[0]
+    mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
+    ctx = _lib.default_context()
+    L = _lib.lib()
+    out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
+    d_rec = ctx.alloc(rec.nbytes)
+    d_out = ctx.alloc(out.nbytes)
+    try:
+        ctx.upload(d_rec, rec)
+        _lib.check(L.spiht_dequant_idwt_batch_f64(ctx.handle, C.c_void_p(d_rec), 1, c, h, w, wid, mid,
+                                                  -1 if level is None else int(level),
+                                                  float(spiht_settings.quantization_scale), mults_p, C.c_void_p(d_out)))
+        ctx.download(out, d_out)
+    finally:
+        ctx.free(d_rec)
+        ctx.free(d_out)
+    rec_image = out
+    color_model = spiht_settings.color_model
+    if color_model is not None:
+        rec_image = color_models.convert(rec_image, color_model, "RGB")
+    return rec_image

@@ -1,0 +1,170 @@
+"""GPU parity tests of the SPIHT list coder (through the C ABI) against the CPU oracle: bit-exact streams,
+max_n and decoded int32 arrays."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import synth_coeffs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+UNLIMITED = 99999999999999999
+
+
+def _check_encode(O, x, lh, lw, mb):
+    import spiht_amd
+    d_ref, n_ref, nb_ref = O.encode_nbits(x, lh, lw, mb)
+    d, n = spiht_amd.encode(x, lh, lw, mb)
+    assert n == n_ref
+    assert len(d) == len(d_ref) == (nb_ref + 7) // 8
+    if d != d_ref:
+        a, b = np.frombuffer(d, np.uint8), np.frombuffer(d_ref, np.uint8)
+        first = int(np.nonzero(a != b)[0][0])
+        raise AssertionError("stream differs at byte %d of %d (bit budget %d)" % (first, len(d), mb))
+    return d, n
+
+
+def _check_decode(O, d, n, shape, lh, lw):
+    import spiht_amd
+    c, h, w = shape
+    r_ref = O.decode(d, n, c, h, w, lh, lw)
+    r = spiht_amd.decode(d, n, c, h, w, lh, lw)
+    assert r.dtype == np.int32 and r.shape == (c, h, w) and r.flags.c_contiguous
+    if not np.array_equal(r, r_ref):
+        bad = np.argwhere(r != r_ref)
+        raise AssertionError("decoded array differs at %d cells, first %s: got %d want %d (stream %d bytes)"
+                             % (len(bad), bad[0], r[tuple(bad[0])], r_ref[tuple(bad[0])], len(d)))
+    return r
+
+
+def test_known_answer_vectors(oracle):
+    import spiht_amd
+    x = 32 * np.ones((1, 16, 16), np.int32)
+    d, n = spiht_amd.encode(x, 2, 2, 10000)
+    assert n == 5 and d == b"\xff" * 73 + b"\x3f" + b"\x00" * 160  # encoder_decoder.rs:865-875 / App. C
+    assert np.array_equal(spiht_amd.decode(d, n, 1, 16, 16, 2, 2), x)
+    x = np.array([[[26, 6, 13, 10], [-7, 7, 6, 4], [4, -4, 4, -3], [2, -2, -2, 0]]], np.int32)
+    d, n = spiht_amd.encode(x, 2, 2, UNLIMITED)
+    assert (d.hex(), n) == ("03f8f0fec7a12b7d200302", 4)
+    assert np.array_equal(spiht_amd.decode(d, n, 1, 4, 4, 2, 2), x)
+    for mb, row0 in [(8, [24, 0, 0, 0]), (16, [24, 0, 12, 12]), (24, [24, 6, 12, 12])]:
+        d, n = spiht_amd.encode(x, 2, 2, mb)
+        assert spiht_amd.decode(d, n, 1, 4, 4, 2, 2)[0, 0].tolist() == row0
+
+
+def test_roundtrip_like_rust_tests(oracle):
+    """encoder_decoder.rs:878-985: lossless on dyadic shapes, ll = 2x2"""
+    import spiht_amd
+    x = 32 * np.ones((1, 16, 16), np.int32)
+    x[:, 1::2, :] *= -1
+    d, n = spiht_amd.encode(x, 2, 2, 10000)
+    assert np.array_equal(spiht_amd.decode(d, n, 1, 16, 16, 2, 2), x)
+    rng = np.random.default_rng(42)
+    for shape in [(1, 8, 8), (4, 32, 32)]:
+        for _ in range(6):
+            a = rng.normal(0, 16, shape).astype(np.int32)
+            d, n = _check_encode(oracle, a, 2, 2, 10000000)
+            assert np.array_equal(spiht_amd.decode(d, n, *shape, 2, 2), a)
+
+
+SHAPES = [  # c, h, w, ll_h, ll_w
+    (1, 8, 8, 2, 2), (1, 16, 16, 2, 2), (2, 16, 16, 4, 4), (3, 13, 17, 3, 5), (1, 21, 19, 5, 3), (3, 24, 40, 3, 5),
+    (1, 32, 32, 2, 2), (2, 11, 23, 4, 6), (1, 4, 4, 2, 2), (3, 33, 29, 6, 5), (1, 8, 8, 4, 4), (1, 6, 6, 3, 3),
+    (1, 64, 64, 2, 2), (3, 70, 100, 5, 7), (1, 129, 65, 9, 5), (4, 48, 48, 6, 6), (1, 300, 200, 3, 2),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_encode_decode_parity_small(oracle, shape):
+    c, h, w, lh, lw = shape
+    rng = np.random.default_rng(hash(shape) % 2**32)
+    xs = [synth_coeffs(5, c, h, w, lh, lw, scale=400.0), rng.normal(0, 16, (c, h, w)).astype(np.int32)]
+    z = np.zeros((c, h, w), np.int32)
+    z[0, h - 1, w // 2] = -3
+    xs.append(z)
+    for x in xs:
+        _, _, total = oracle.encode_nbits(x, lh, lw, UNLIMITED)
+        budgets = [UNLIMITED, 0, 1, 2, 7, 8, 9, total, total - 1, total + 5] + \
+            [int(v) for v in rng.integers(1, max(2, total), 6)]
+        for mb in budgets:
+            if mb < 0:
+                continue
+            d, n = _check_encode(oracle, x, lh, lw, mb)
+            _check_decode(oracle, d, n, (c, h, w), lh, lw)
+
+
+def test_all_zero_and_tiny(oracle):
+    import spiht_amd
+    x = np.zeros((2, 8, 8), np.int32)
+    d, n = _check_encode(oracle, x, 2, 2, UNLIMITED)
+    _check_decode(oracle, d, n, (2, 8, 8), 2, 2)
+    assert np.array_equal(spiht_amd.decode(b"", 5, 1, 8, 8, 2, 2), np.zeros((1, 8, 8), np.int32))
+
+
+def test_strided_views(oracle):
+    rng = np.random.default_rng(1)
+    big = rng.normal(0, 40, (3, 40, 64)).astype(np.int32)
+    for view in [big[:, ::2, :], big[:, :, ::2], big[::2], big.transpose(0, 2, 1), big[:, ::-1, :]]:
+        c, h, w = view.shape
+        _check_encode(oracle, view, 2, 2, 5000)
+
+
+def test_prefix_truncation_and_pad_bits(oracle):
+    """make_gif.py:46-55 decodes byte prefixes; lib.rs:38 makes the pad bits data.
+    13x17 / ll 3x5 has duplicated tree nodes (Q4)."""
+    for (c, h, w, lh, lw) in [(3, 13, 17, 3, 5), (1, 32, 32, 2, 2), (2, 26, 38, 13, 19)]:
+        x = synth_coeffs(9, c, h, w, lh, lw, scale=500.0)
+        full, n, total = oracle.encode_nbits(x, lh, lw, UNLIMITED)
+        for nb in list(range(0, min(len(full), 40))) + list(range(max(0, len(full) - 12), len(full) + 1)):
+            _check_decode(oracle, full[:nb], n, (c, h, w), lh, lw)
+        # every bit budget in a window: the cut lands on sig bits, sign bits, refinement bits
+        for mb in list(range(1, 130)) + list(range(max(1, total - 70), total + 2)):
+            d, n2 = _check_encode(oracle, x, lh, lw, mb)
+            _check_decode(oracle, d, n2, (c, h, w), lh, lw)
+
+
+def test_decode_arbitrary_bytes_even_ll(oracle):
+    """Any byte string is a valid input when the tree has no duplicated nodes (even LL)."""
+    rng = np.random.default_rng(5)
+    for (c, h, w, lh, lw) in [(1, 16, 16, 2, 2), (2, 24, 40, 4, 6)]:
+        for ln in [1, 3, 17, 200]:
+            d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+            _check_decode(oracle, d, 9, (c, h, w), lh, lw)
+
+
+def test_golden_python_twin_inputs_rust_rule(oracle):
+    """The fixture inputs captured from spiht_py.py, coded with the Rust rule on GPU == oracle."""
+    g = np.load(os.path.join(GOLD, "spiht_py_loops.npz"))
+    for k in range(int(g["ncases"])):
+        p = "case%02d_" % k
+        arr, lh, lw, mb = g[p + "arr"], int(g[p + "ll_h"]), int(g[p + "ll_w"]), int(g[p + "max_bits"])
+        d, n = _check_encode(oracle, arr, lh, lw, mb)
+        _check_decode(oracle, d, n, arr.shape, lh, lw)
+
+
+def test_panics_and_errors():
+    import spiht_amd
+    from spiht_amd.spiht import PanicException
+    x = np.ones((1, 8, 8), np.int32)
+    with pytest.raises(PanicException):
+        spiht_amd.encode(x, 1, 2, 100)
+    with pytest.raises(PanicException):
+        spiht_amd.encode(x, 2, 1, 100)
+    with pytest.raises(PanicException):
+        spiht_amd.encode(np.ones((1, 6, 8), np.int32), 4, 2, 100)  # offspring outside the array
+    with pytest.raises(PanicException):
+        spiht_amd.encode(np.ones((0, 8, 8), np.int32), 2, 2, 100)
+    with pytest.raises(ValueError):
+        spiht_amd.encode(np.full((1, 8, 8), 2**30, np.int32), 2, 2, 100)
+
+
+def test_medium_realistic(oracle):
+    """A 3x293x501 array with ll 13x19 (the odd/odd geometry of the 1080p config, Q3+Q4)."""
+    x = synth_coeffs(42, 3, 293, 501, 13, 19)
+    for mb in [12345, 100000, UNLIMITED]:
+        d, n = _check_encode(oracle, x, 13, 19, mb)
+        _check_decode(oracle, d, n, x.shape, 13, 19)
+    full, n, total = oracle.encode_nbits(x, 13, 19, UNLIMITED)
+    for nb in [1000, 12345 // 8, len(full) // 3, len(full) - 1]:
+        _check_decode(oracle, full[:nb], n, x.shape, 13, 19)

@@ -1,0 +1,181 @@
+"""CPU tests: the oracle against the reference's own known answers and the committed golden fixtures.
+
+Fixtures under tests/golden/ were captured by tests/golden/make_golden.py from the reference imported in
+place (spiht/spiht_py.py list logic; spiht/spiht_wrapper.py + PyWavelets 1.1.1)."""
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+WNAMES = ["bior2.2", "bior4.4", "bior6.8", "haar"]
+
+
+def test_bit_helpers_rust_known_answers(oracle):
+    O = oracle
+    # encoder_decoder.rs:851-862
+    assert O.is_bit_set(32, 5)
+    for n in range(5):
+        assert not O.is_bit_set(32, n)
+    assert O.is_bit_set(-69, 6)
+    assert not O.is_bit_set(3590854, 8)
+    # :994-1000
+    assert O.set_bit(-96, 5, False) == -64
+    assert O.set_bit(-96, 5, True) == -96
+    assert O.set_bit(-64, 5, True) == -96
+    assert O.set_bit(96, 5, True) == 96
+    assert O.set_bit(96, 5, False) == 64
+    # :1003-1009
+    assert not O.is_element_sig(-21, 6)
+    assert O.is_element_sig(-64, 6)
+    assert O.is_element_sig(64, 6)
+    assert not O.is_element_sig(55, 6)
+
+
+def test_set_bit_keeps_sign(oracle):
+    # encoder_decoder.rs:1012-1024 (own seed: the crate's SmallRng stream is not reproducible here)
+    rng = np.random.default_rng(420)
+    for _ in range(420):
+        x = int(rng.integers(-2**31 + 1, 2**31 - 1))
+        n = int(rng.integers(0, 16))
+        bit = bool(rng.integers(0, 2))
+        y = oracle.set_bit(x, n, bit)
+        assert (y >= 0) == (x >= 0) or y == 0
+        assert oracle.is_bit_set(y, n) == bit
+
+
+def test_simple_encode_max_n(oracle):
+    # encoder_decoder.rs:865-875
+    x = 32 * np.ones((1, 16, 16), np.int32)
+    data, max_n, nbits = oracle.encode_nbits(x, 2, 2, 10000)
+    assert max_n == 5
+    # SURVEY.md App. C vector 1 (derived)
+    assert nbits == 1870
+    assert data == b"\xff" * 73 + b"\x3f" + b"\x00" * 160
+
+
+def test_appendix_c_vector2(oracle):
+    x = np.array([[[26, 6, 13, 10], [-7, 7, 6, 4], [4, -4, 4, -3], [2, -2, -2, 0]]], np.int32)
+    data, max_n, nbits = oracle.encode_nbits(x, 2, 2, 99999999999999999)
+    assert (max_n, nbits) == (4, 83)
+    assert data.hex() == "03f8f0fec7a12b7d200302"
+    assert np.array_equal(oracle.decode(data, max_n, 1, 4, 4, 2, 2), x)
+    for mb, row0 in [(8, [24, 0, 0, 0]), (16, [24, 0, 12, 12]), (24, [24, 6, 12, 12])]:
+        d, mn, nb = oracle.encode_nbits(x, 2, 2, mb)
+        assert nb == mb
+        assert oracle.decode(d, mn, 1, 4, 4, 2, 2)[0, 0].tolist() == row0
+
+
+def test_roundtrip_dyadic(oracle):
+    # encoder_decoder.rs:878-985: lossless on dyadic shapes with ll=2x2
+    x = 32 * np.ones((1, 16, 16), np.int32)
+    x[:, 1::2, :] *= -1
+    d, mn = oracle.encode(x, 2, 2, 10000)
+    assert np.array_equal(oracle.decode(d, mn, 1, 16, 16, 2, 2), x)
+    rng = np.random.default_rng(42)
+    for shape in [(1, 8, 8), (4, 32, 32)]:
+        for _ in range(10):
+            a = rng.normal(0, 16, shape).astype(np.int32)
+            d, mn = oracle.encode(a, 2, 2, 10000000)
+            assert np.array_equal(oracle.decode(d, mn, *shape, 2, 2), a)
+
+
+def test_panics(oracle):
+    x = np.ones((1, 8, 8), np.int32)
+    with pytest.raises(oracle.OraclePanic):
+        oracle.encode(x, 1, 2, 100)
+    with pytest.raises(oracle.OraclePanic):
+        oracle.decode(b"\x00", 3, 1, 8, 8, 2, 1)
+
+
+def test_start_plane_f32_quirk(oracle):
+    # f32 log2 + truncation
+    assert oracle.start_plane(0) == 0
+    assert oracle.start_plane(1) == 0
+    assert oracle.start_plane(32) == 5
+    assert oracle.start_plane(63) == 5
+    assert oracle.start_plane(2**21 - 1) == 21
+    assert oracle.start_plane(2**20 - 1) == 19
+
+
+def test_strided_input(oracle):
+    rng = np.random.default_rng(3)
+    big = rng.normal(0, 30, (2, 16, 32)).astype(np.int32)
+    view = big[:, :, ::2]
+    d1, n1 = oracle.encode(view, 2, 2, 10**9)
+    d2, n2 = oracle.encode(np.ascontiguousarray(view), 2, 2, 10**9)
+    assert (d1, n1) == (d2, n2)
+
+
+def test_list_logic_matches_reference_python_twin(oracle):
+    """spiht/spiht_py.py encode/decode loops == oracle in py-compat mode, bit for bit."""
+    g = np.load(os.path.join(GOLD, "spiht_py_loops.npz"))
+    n = int(g["ncases"])
+    assert n >= 10
+    ndiff = 0
+    for k in range(n):
+        p = "case%02d_" % k
+        arr, lh, lw, mb = g[p + "arr"], int(g[p + "ll_h"]), int(g[p + "ll_w"]), int(g[p + "max_bits"])
+        c, h, w = arr.shape
+        d, mn, nb = oracle.encode_nbits(arr, lh, lw, mb, rule=oracle.RULE_PY)
+        bits = oracle.bytes_to_bits(d)[:nb]
+        gb = g[p + "bits"]
+        assert mn == int(g[p + "max_n"])
+        assert np.array_equal(gb[:nb], bits) and not gb[nb:].any()
+        rec = oracle.decode_bits(gb, mn, c, h, w, lh, lw, rule=oracle.RULE_PY)
+        assert np.array_equal(rec, g[p + "rec"])
+        d2, _, _ = oracle.encode_nbits(arr, lh, lw, mb, rule=oracle.RULE_RUST)
+        ndiff += d2 != d
+    assert ndiff > 0  # the two l_exists rules really differ
+    # helper functions of the twin
+    for x, nn, b, y in g["helper_set_bit"]:
+        assert oracle.set_bit(int(x), int(nn), int(b)) == int(y)
+    for row in g["helper_offspring"]:
+        i, j, h, w, lh, lw = [int(v) for v in row[:6]]
+        exp = row[6:].reshape(4, 2)
+        got = oracle.get_offspring(i, j, h, w, lh, lw)
+        if exp[0, 0] < 0:
+            assert got is None
+        else:
+            assert got == [tuple(int(v) for v in r) for r in exp]
+
+
+def test_filter_banks_and_geometry_match_pywt(oracle):
+    w = np.load(os.path.join(GOLD, "wrapper_pywt.npz"))
+    for name in WNAMES:
+        assert np.array_equal(np.array(oracle.wavelet_filters(name)), w["fb_" + name])
+    for row in w["geometry"]:
+        H, W, wi, lv, llh, llw, eh, ew, nlev = [int(v) for v in row]
+        g = oracle.geometry(H, W, WNAMES[wi], None if lv < 0 else lv)
+        assert (g["ll_h"], g["ll_w"], g["enc_h"], g["enc_w"], g["level"]) == (llh, llw, eh, ew, nlev)
+
+
+def _wrapper_cases():
+    w = np.load(os.path.join(GOLD, "wrapper_pywt.npz"))
+    for k in range(int(w["ncases"])):
+        p = "case%02d_" % k
+        c, H, W, lv = [int(v) for v in w[p + "meta"]]
+        m = w[p + "mults"]
+        yield dict(img=w[p + "img"], coeffs=w[p + "coeffs"], farr=w[p + "farr"], ll=tuple(int(v) for v in w[p + "ll"]),
+                   rec=w[p + "rec"], rec_img=w[p + "rec_img"], c=c, H=H, W=W, level=None if lv < 0 else lv,
+                   wavelet=str(w[p + "wavelet"]), mode=str(w[p + "mode"]), q=float(w[p + "q"]),
+                   mults=None if m.size == 0 else m)
+
+
+def test_dwt_front_and_back_half_match_reference_wrapper(oracle):
+    """pixels -> int32 coefficients (wrapper:163-172) and int32 rec -> pixels (wrapper:259-276) against
+    arrays captured from the reference wrapper running on PyWavelets 1.1.1."""
+    n = 0
+    for cs in _wrapper_cases():
+        arr, g = oracle.wavedec2_array(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
+        assert (g["ll_h"], g["ll_w"]) == cs["ll"]
+        # tolerance: pywt sums boundary taps in another order: <= a few ulp of O(10) values
+        assert np.abs(arr - cs["farr"]).max() < 2e-14
+        co = oracle.quantize(arr, cs["q"], cs["mults"])
+        assert np.array_equal(co, cs["coeffs"])
+        ri = oracle.waverec2_array(oracle.dequantize(cs["rec"], cs["q"], cs["mults"]), cs["H"], cs["W"], cs["wavelet"],
+                                   cs["level"])
+        assert ri.shape == cs["rec_img"].shape
+        assert np.abs(ri - cs["rec_img"]).max() < 1e-13
+        n += 1
+    assert n >= 10
