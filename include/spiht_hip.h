@@ -28,7 +28,7 @@ enum {
     SPIHT_ERR_ARG = 6,       /* null pointer / negative size / unknown wavelet or mode */
     SPIHT_ERR_MAGNITUDE = 7, /* max|x| >= 2^30: outside the range the reference handles */
     SPIHT_ERR_INTERNAL = 8,  /* device-side list overflow guard tripped (a bug, never expected) */
-    SPIHT_ERR_TOO_LARGE = 9, /* c*h*w >= 2^31 or stream >= 2^32 bits */
+    SPIHT_ERR_TOO_LARGE = 9, /* c*h*w >= 2^30 or stream >= 2^32 bits */
     SPIHT_ERR_NOMEM = 10
 };
 

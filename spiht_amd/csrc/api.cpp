@@ -203,7 +203,7 @@ static int make_geom(int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll_w
     int64_t need_h = (ll_h % 2 == 0) ? 2 * ll_h : 2 * ll_h - 1;
     int64_t need_w = (ll_w % 2 == 0) ? 2 * ll_w : 2 * ll_w - 1;
     if (h < need_h || w < need_w) return SPIHT_ERR_SHAPE;
-    if ((double)c * (double)h * (double)w >= 2147483648.0) return SPIHT_ERR_TOO_LARGE;
+    if ((double)c * (double)h * (double)w >= 1073741824.0) return SPIHT_ERR_TOO_LARGE;
     g->c = (int32_t)c; g->h = (int32_t)h; g->w = (int32_t)w;
     g->ll_h = (int32_t)ll_h; g->ll_w = (int32_t)ll_w;
     g->hw = (uint32_t)(h * w);
@@ -260,7 +260,7 @@ static void list_caps(const Geom &g, uint64_t max_bits, ListCaps *caps, uint64_t
     instance_counts(g, &nodes, &parents);
     uint64_t roots = (uint64_t)g.c * g.ll_h * g.ll_w;
     uint64_t mb = max_bits;
-    uint64_t lip = nodes, lsp = nodes, lis = parents;
+    uint64_t lip = nodes, lsp = nodes, lis = parents + 4 * roots;  // + leaf A entries under root B entries (Q5)
     if (mb < (1ull << 40)) {
         lip = std::min(lip, roots + mb);
         lsp = std::min(lsp, mb / 2 + 1);
@@ -288,7 +288,7 @@ extern "C" const char *spiht_strerror(int s) {
     case SPIHT_ERR_ARG: return "invalid argument";
     case SPIHT_ERR_MAGNITUDE: return "coefficient magnitude >= 2^30 is outside the supported range";
     case SPIHT_ERR_INTERNAL: return "internal list capacity guard tripped";
-    case SPIHT_ERR_TOO_LARGE: return "array or stream too large (c*h*w must be < 2^31, stream < 2^32 bits)";
+    case SPIHT_ERR_TOO_LARGE: return "array or stream too large (c*h*w must be < 2^30, stream < 2^32 bits)";
     case SPIHT_ERR_NOMEM: return "out of device memory";
     default: return "unknown status";
     }

@@ -36,14 +36,17 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
 struct Geom {
     int32_t c, h, w, ll_h, ll_w;
     uint32_t hw;  // h*w
-    uint32_t n;   // c*h*w  (< 2^31)
+    uint32_t n;   // c*h*w  (< 2^30)
     uint32_t pad;
     FastDiv div_w, div_hw;
 };
 
-// List entry: bit 31 = type A (1) / type B (0) for LIS entries; low 31 bits = linear index k*hw + i*w + j.
+// List entry: bit 31 = type A (1) / type B (0) for LIS entries; bit 30 = "leaf": a type-A entry whose node
+// has no offspring (the reference still queues it when its parent's B entry fires; it emits a 0 in every
+// plane and can never fire, encoder_decoder.rs:229-239); low 30 bits = linear index k*hw + i*w + j.
 #define ENT_A 0x80000000u
-#define ENT_IDX 0x7FFFFFFFu
+#define ENT_LEAF 0x40000000u
+#define ENT_IDX 0x3FFFFFFFu
 
 // Per-slot scratch of the list coder.  A "slot" serves one image at a time.
 struct ListCaps {

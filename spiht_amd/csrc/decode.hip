@@ -82,8 +82,7 @@ __device__ __forceinline__ void decomp(const Geom &g, uint32_t idx, uint32_t &k,
     j = r - i * (uint32_t)g.w;
 }
 
-__device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32_t i, uint32_t j) {
-    uint32_t r, cc;
+__device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32_t i, uint32_t j, uint32_t &r, uint32_t &cc) {
     if (i < (uint32_t)g.ll_h && j < (uint32_t)g.ll_w) {
         r = (i & 1u) * (uint32_t)g.ll_h + (i & ~1u);
         cc = (j & 1u) * (uint32_t)g.ll_w + (j & ~1u);
@@ -92,6 +91,10 @@ __device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32
         cc = 2 * j;
     }
     return k * g.hw + r * (uint32_t)g.w + cc;
+}
+
+__device__ __forceinline__ uint32_t make_a_entry(uint32_t idx, uint32_t ci, uint32_t cj, uint32_t H, uint32_t W) {
+    return idx | ENT_A | ((2 * ci + 1 < H && 2 * cj + 1 < W) ? 0u : ENT_LEAF);
 }
 
 struct BitSrc {
@@ -288,7 +291,9 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                     const uint32_t e = act ? cur[e0 + lane] : 0u;
                     const uint32_t idx = e & ENT_IDX;
                     const bool isA = (e & ENT_A) != 0;
-                    const uint64_t TA = __ballot(act && isA);
+                    // only a type-A entry WITH offspring is followed by child bits when it fires
+                    const bool leaf = (e & ENT_LEAF) != 0;
+                    const uint64_t TA = __ballot(act && isA && !leaf);
                     uint32_t mypos = POS_INVALID;
                     ensure(sh, bs, P, 64 * 9 + 192, lane);  // whole window span staged: no refill during the walk
                     // ---- position walk (uniform control flow) ----
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                     const bool have = act && mypos != POS_INVALID && mypos < nbits;
                     bool stop = act && !have;
                     uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0, nT = 0;
-                    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0;
+                    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
                     bool fired = false;
                     if (have) {
                         const uint32_t avail = nbits - mypos;
@@ -345,10 +350,14 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                         fired = bits & 1u;
                         if (!fired) {
                             nR = 1;
+                        } else if (leaf) {
+                            // a set with no offspring cannot be significant in a real stream; the reference drops
+                            // the entry (no offspring to read, has_descendents_past_offspring is false too)
+                            fired = false;
                         } else {
                             uint32_t k, ii, jj;
                             decomp(g, idx, k, ii, jj);
-                            cb = child_base(g, k, ii, jj);
+                            cb = child_base(g, k, ii, jj, cr, ccol);
                             if (!isA) {
                                 nQ = 4;
                             } else {
@@ -388,14 +397,16 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                     if (nxt_len + tQ > a.caps.lis || ret_len + tR > a.caps.lis || lip_len + tLIP > a.caps.lip ||
                         lsp_len + tLSP > a.caps.lsp) { bad = true; done = true; break; }
                     if (have) {
-                        if (!fired) {
+                        if (nR) {
                             ret[ret_len + ((uint32_t)(ex >> 12) & 0xfffu)] = e;
+                        } else if (!fired) {
+                            // fired leaf: dropped
                         } else if (!isA) {
                             uint32_t oq = nxt_len + ((uint32_t)ex & 0xfffu);
-                            nxt[oq] = cb | ENT_A;
-                            nxt[oq + 1] = (cb + 1) | ENT_A;
-                            nxt[oq + 2] = (cb + W) | ENT_A;
-                            nxt[oq + 3] = (cb + W + 1) | ENT_A;
+                            nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
+                            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
+                            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
+                            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
                         } else {
                             uint32_t ol = lip_len + ((uint32_t)(ex >> 24) & 0xfffu);
                             uint32_t os = lsp_len + ((uint32_t)(ex >> 36) & 0xfffu);

@@ -95,9 +95,9 @@ __device__ __forceinline__ void decomp(const Geom &g, uint32_t idx, uint32_t &k,
     j = r - i * (uint32_t)g.w;
 }
 
-// linear index (within the image) of offspring (0,0); the others are +1, +w, +w+1  (encoder_decoder.rs:43-75)
-__device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32_t i, uint32_t j) {
-    uint32_t r, cc;
+// offspring (0,0) of node (i,j): row r, column cc (the others are +1 in either direction); returns its linear
+// index within the image  (encoder_decoder.rs:43-75)
+__device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32_t i, uint32_t j, uint32_t &r, uint32_t &cc) {
     if (i < (uint32_t)g.ll_h && j < (uint32_t)g.ll_w) {
         r = (i & 1u) * (uint32_t)g.ll_h + (i & ~1u);
         cc = (j & 1u) * (uint32_t)g.ll_w + (j & ~1u);
@@ -106,6 +106,11 @@ __device__ __forceinline__ uint32_t child_base(const Geom &g, uint32_t k, uint32
         cc = 2 * j;
     }
     return k * g.hw + r * (uint32_t)g.w + cc;
+}
+
+// type-A entry for child (ci,cj) with linear index idx: flagged leaf when it has no offspring of its own
+__device__ __forceinline__ uint32_t make_a_entry(uint32_t idx, uint32_t ci, uint32_t cj, uint32_t H, uint32_t W) {
+    return idx | ENT_A | ((2 * ci + 1 < H && 2 * cj + 1 < W) ? 0u : ENT_LEAF);
 }
 
 // `(max as f32).log2() as u8`  (encoder_decoder.rs:166) with the host libm's rounding (table from the host)
@@ -222,14 +227,14 @@ __global__ __launch_bounds__(BLOCK) void k_encode(EncArgs a) {
                     uint32_t e = act ? cur[r] : 0;
                     uint32_t idx = e & ENT_IDX;
                     bool isA = (e & ENT_A) != 0;
-                    uint32_t code = act ? (isA ? DM[idx] : LM[idx]) : 0;
+                    uint32_t code = (act && !(e & ENT_LEAF)) ? (isA ? DM[idx] : LM[idx]) : 0;
                     bool fired = act && (int)code > n;
                     uint32_t bits = 0, nb = act ? 1u : 0u, nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
-                    uint32_t cb = 0, sigm = 0;
+                    uint32_t cb = 0, sigm = 0, cr = 0, ccol = 0;
                     if (fired) {
                         uint32_t k, i, j;
                         decomp(g, idx, k, i, j);
-                        cb = child_base(g, k, i, j);
+                        cb = child_base(g, k, i, j, cr, ccol);
                         bits = 1u;
                         if (isA) {
                             int32_t xc[4];
@@ -278,10 +283,10 @@ __global__ __launch_bounds__(BLOCK) void k_encode(EncArgs a) {
                             }
                             if (nQ) nxt[oq] = idx;  // type B
                         } else {
-                            nxt[oq] = (cb) | ENT_A;
-                            nxt[oq + 1] = (cb + 1) | ENT_A;
-                            nxt[oq + 2] = (cb + W) | ENT_A;
-                            nxt[oq + 3] = (cb + W + 1) | ENT_A;
+                            nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
+                            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
+                            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
+                            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
                         }
                     } else if (act) {
                         ret[ret_len + ((uint32_t)(ex >> 27) & 0x7ffu)] = e;
