@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SPIHT image hot path on MI355X.
+
+Metric (BASELINE.json): Mpixels/s encode+decode at fixed bpp (pixels = H*W per image, not x channels).
+Workload: 1920x1080 RGB float64 images, bior2.2 / reflect / level 7 / q=50, 0.5 bpp (max_bits = 1 036 800):
+BASELINE config 2's image, --batch of them per GPU (default 256 = config 4's per-GPU shard, weak scaling).
+One step = every image of the batch goes pixels -> DWT -> quantise -> SPIHT stream -> SPIHT decode ->
+dequantise -> inverse DWT -> pixels, all resident in HBM (inputs are uploaded before the timed region).
+With N > 1 each rank codes its own shard and the streams are all-gathered (RCCL) between encode and decode.
+
+Prints ONE JSON line on rank 0 (see the task contract) with two extra objects:
+  roofline      achieved vs peak HBM bandwidth of the dominant HBM-bound kernel (forward DWT, level 1),
+                timed with HIP events on the library's own stream inside the timed region
+  cpu_baseline  the CPU oracle (a port of the reference algorithm; the Rust reference cannot be built here)
+                timed on a bounded sample of the same workload, one core
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+H, W, C_IMG = 1080, 1920, 3
+LEVEL, BPP = 7, 0.5
+WAVELET, MODE, QSCALE = "bior2.2", "reflect", 50.0
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synth_image(seed, c, h, w):
+    """SURVEY.md 8(d) pixel-domain generator (mimics spiht/utils.py imload: uint8/255 as float64)."""
+    rng = np.random.default_rng(seed)
+    g = rng.standard_normal((c, h, w))
+    b = np.cumsum(np.cumsum(g, axis=1), axis=2)
+    mn = b.min(axis=(1, 2), keepdims=True)
+    mx = b.max(axis=(1, 2), keepdims=True)
+    b = (b - mn) / (mx - mn)
+    b = b + 0.02 * rng.standard_normal((c, h, w))
+    return np.round(np.clip(b, 0, 1) * 255).astype(np.uint8) / 255
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU baseline codes (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    dist = torch = None
+    if N > 1 or world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        world = dist.get_world_size()
+
+    from spiht_amd import _lib
+    from spiht_amd.batch import BatchCodec, DeviceArray
+    from spiht_amd.spiht_wrapper import SpihtSettings
+
+    ctx = _lib.default_context(local_rank)
+    B = args.batch
+    max_bits = int(H * W * BPP)  # demonstrate.py:50
+    codec = BatchCodec(C_IMG, H, W, SpihtSettings(WAVELET, QSCALE, MODE), LEVEL, max_bits, ctx=ctx)
+    g = codec.geom
+    slot = codec.slot_stride
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    nd = max(1, min(args.distinct, B))
+    base = [synth_image(1000 + rank * nd + i, C_IMG, H, W) for i in range(nd)]
+    d_img = DeviceArray(ctx, (B, C_IMG, H, W), np.float64)
+    per = C_IMG * H * W * 8
+    for b in range(B):
+        d_img.upload(base[b % nd], offset_bytes=b * per)
+    d_rec_img = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
+    d_nbits = DeviceArray(ctx, (B,), np.uint64)
+    d_nbytes = DeviceArray(ctx, (B,), np.uint64)
+    d_maxn = DeviceArray(ctx, (B,), np.uint8)
+    if dist is not None:
+        out_t = torch.zeros((B, slot), dtype=torch.uint8, device="cuda")
+        gathered = torch.zeros((world * B, slot), dtype=torch.uint8, device="cuda")
+        out_ptr = out_t.data_ptr()
+    else:
+        d_out = DeviceArray(ctx, (B, slot), np.uint8)
+        out_ptr = d_out.ptr
+
+    def step():
+        codec.encode_device(d_img.ptr, B, out_ptr, d_nbits.ptr, d_maxn.ptr)
+        if dist is not None:
+            ctx.synchronize()
+            dist.all_gather_into_tensor(gathered, out_t)  # the one collective of the path
+            torch.cuda.synchronize()
+        codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
+        codec.decode_device(out_ptr, d_nbytes.ptr, d_maxn.ptr, B, d_rec_img.ptr)
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ctx.reset_timing()
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    ctx.set_timing(False)
+    stages = ctx.timing()
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- correctness of what was timed (outside the timed region) ----
+    nbits = d_nbits.download()
+    maxn = d_maxn.download()
+    rec0 = np.empty((C_IMG, g["rec_h"], g["rec_w"]), np.float64)
+    ctx.download(rec0, d_rec_img.ptr)
+    mae = float(np.abs(rec0[:, :H, :W] - base[0]).mean())
+
+    result = None
+    if rank == 0:
+        total_images = world * B * args.steps
+        mpix = total_images * H * W / dt / 1e6
+        h1, w1 = (H + 6 - 1) // 2, (W + 6 - 1) // 2
+        # algorithmic bytes of one forward-DWT level-1 launch over the whole batch:
+        # read the float64 image once, write LL as float64 and the three detail bands as int32
+        dwt_bytes = B * C_IMG * (H * W * 8 + h1 * w1 * 8 + 3 * h1 * w1 * 4)
+        ms_l1, n_l1 = stages.get("dwt_level1", (0.0, 0))
+        avg_ms = ms_l1 / n_l1 if n_l1 else float("nan")
+        achieved = dwt_bytes / (avg_ms * 1e-3) / 1e9 if n_l1 else float("nan")
+        result = {
+            "metric": "Mpixels/sec encode+decode at fixed bpp; bitstream-exact vs Rust ref",
+            "value": round(mpix, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 DWT / int32 bit-plane coding",
+            "data": "synthetic",
+            "config": {"workload": "cfg2 image (1920x1080 RGB, bior2.2 reflect level 7, q=50, 0.5 bpp) x %d per GPU "
+                                   "(cfg4 shard), encode+decode, HBM-resident" % B,
+                       "images_per_gpu": B, "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
+                       "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]]},
+            "roofline": {"bound": "hbm", "kernel": "k_dwt_level<6> (forward DWT level 1, fused quantise)",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4)},
+            "stages_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in stages.items() if v[1]},
+            "check": {"nbits_all_equal_budget": bool((nbits == max_bits).all()), "max_n": int(maxn[0]),
+                      "mean_abs_err_image0": round(mae, 5)},
+        }
+
+        # ---- CPU baseline: the oracle (port of the reference algorithm) on a bounded sample, one core ----
+        if args.cpu_sample > 0:
+            from oracle import oracle as O
+            ns = min(args.cpu_sample, nd)
+            tc = time.perf_counter()
+            streams = []
+            for i in range(ns):
+                data, mn, _ = O.encode_image(base[i], WAVELET, MODE, LEVEL, QSCALE, None, max_bits)
+                streams.append((data, mn))
+            t_enc = time.perf_counter() - tc
+            tc = time.perf_counter()
+            for i in range(ns):
+                O.decode_image(streams[i][0], streams[i][1], C_IMG, H, W, WAVELET, LEVEL, QSCALE, None)
+            t_dec = time.perf_counter() - tc
+            result["cpu_baseline"] = {
+                "value": round(ns * H * W / (t_enc + t_dec) / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                "kind": "port",
+                "sample": "%d of the same 1080p images, encode %.2fs + decode %.2fs, oracle/liboracle.so (gcc -O3), "
+                          "host has %d cores" % (ns, t_enc, t_dec, os.cpu_count() or 0)}
+            # bit-exactness of the timed GPU output against the oracle, image 0 of rank 0
+            out0 = np.empty(slot, np.uint8)
+            ctx.download(out0, out_ptr)
+            gpu_stream = out0[:(int(nbits[0]) + 7) // 8].tobytes()
+            result["check"]["stream_bit_exact_vs_oracle"] = bool(gpu_stream == streams[0][0] and int(maxn[0]) == streams[0][1])
+            ref_img = O.decode_image(streams[0][0], streams[0][1], C_IMG, H, W, WAVELET, LEVEL, QSCALE, None)
+            result["check"]["decoded_image_bit_exact_vs_oracle"] = bool(np.array_equal(ref_img, rec0))
+        print(json.dumps(result))
+        sys.stdout.flush()
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,10 @@ int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B
 int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
                             int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs);
 
+/* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
+ * counts the decoder takes, without a host round trip. */
+int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes);
+
 /* Thin device-memory helpers so a host language without a HIP binding can drive the batched API. */
 int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr);
 int spiht_dev_free(spiht_ctx *ctx, void *d_ptr);

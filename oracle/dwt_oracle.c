@@ -175,7 +175,10 @@ static void idwt_line(const double *ca, const double *cd, int64_t L, int64_t si,
     int64_t N = 2 * L - F + 2;
     for (int64_t n = 0; n < N; n++) {
         double s = 0.0;
-        for (int64_t k = 0; k < L; k++) {
+        /* only k with tap index t = n+F-2-2k in [0,F) contribute: k in [ceil((n-1)/2), floor((n+F-2)/2)] */
+        int64_t k_hi = (n + F - 2) / 2;
+        if (k_hi > L - 1) k_hi = L - 1;
+        for (int64_t k = n / 2; k <= k_hi; k++) {
             int64_t t = n + F - 2 - 2 * k;
             if (t < 0 || t >= F) continue;
             s += ca[k * si] * lo[t] + cd[k * si] * hi[t];

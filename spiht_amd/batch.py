@@ -1,0 +1,135 @@
+"""Batched, device-resident image codec: the form the throughput metric is measured on.
+
+The reference codes one image per call (spiht_wrapper.encode_image / decode_image).  Here B images of one
+geometry are transformed, quantised and coded in one queue of HIP kernels; pixels, coefficient arrays and
+bitstreams stay in HBM between the stages.  Device buffers may come from this module (hipMalloc through the
+C ABI) or from anyone else (e.g. a torch tensor's data_ptr()) -- the C ABI takes plain pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .spiht_wrapper import EncodingResult, SpihtSettings, _geometry, _mults_arg, _wavelet_mode_ids
+
+
+class DeviceArray:
+    """A hipMalloc'd buffer with a shape and dtype (no arithmetic: storage only)."""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = ctx.alloc(max(self.nbytes, 4))
+
+    def upload(self, arr, offset_bytes=0):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert offset_bytes + arr.nbytes <= self.nbytes
+        self.ctx.upload(self.ptr + offset_bytes, arr)
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            self.ctx.download(out, self.ptr)
+        return out
+
+    def zero(self):
+        self.ctx.memset(self.ptr, 0, self.nbytes)
+
+    def free(self):
+        if self.ptr:
+            self.ctx.free(self.ptr)
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class BatchCodec:
+    """encode/decode B images [B,c,H,W] (float64) at a fixed bit budget.
+
+    settings / level / max_bits have the meaning of spiht_wrapper.encode_image; colour conversion is not
+    applied here (convert before uploading)."""
+
+    def __init__(self, c, H, W, settings=None, level=None, max_bits=None, ctx=None):
+        self.settings = settings if settings is not None else SpihtSettings()
+        self.c, self.H, self.W, self.level = int(c), int(H), int(W), level
+        self.ctx = ctx if ctx is not None else _lib.default_context()
+        self.L = _lib.lib()
+        self.wid, self.mid = _wavelet_mode_ids(self.settings)
+        self.geom = _geometry(H, W, self.wid, level)
+        self.max_bits = 99999999999999999 if max_bits is None else int(max_bits)
+        self.mults, self._mults_p = _mults_arg(self.settings.per_channel_quant_scales, self.c)
+        bound = C.c_uint64()
+        _lib.check(self.L.spiht_encode_bound(self.c, self.geom["enc_h"], self.geom["enc_w"], self.geom["ll_h"],
+                                             self.geom["ll_w"], 0x3FFFFFFF, self.max_bits, C.byref(bound)))
+        self.slot_stride = max(int(bound.value), 4)
+        self._lv = -1 if level is None else int(level)
+
+    # ---- raw device-pointer API (ints) -------------------------------------------------------
+    def encode_device(self, d_img, B, d_out, d_nbits, d_max_n, d_coeffs=None):
+        _lib.check(self.L.spiht_encode_image_batch_f64(
+            self.ctx.handle, C.c_void_p(d_img), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
+            float(self.settings.quantization_scale), self._mults_p, self.max_bits, C.c_void_p(d_out),
+            self.slot_stride, C.c_void_p(d_nbits), C.c_void_p(d_max_n), C.c_void_p(d_coeffs) if d_coeffs else None))
+
+    def decode_device(self, d_data, d_nbytes, d_max_n, B, d_img_out, d_rec=None, slot_stride=None):
+        _lib.check(self.L.spiht_decode_image_batch_f64(
+            self.ctx.handle, C.c_void_p(d_data), self.slot_stride if slot_stride is None else int(slot_stride),
+            C.c_void_p(d_nbytes), C.c_void_p(d_max_n), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
+            float(self.settings.quantization_scale), self._mults_p, C.c_void_p(d_img_out),
+            C.c_void_p(d_rec) if d_rec else None))
+
+    def nbits_to_nbytes(self, d_nbits, B, d_nbytes):
+        _lib.check(self.L.spiht_nbits_to_nbytes(self.ctx.handle, C.c_void_p(d_nbits), int(B), C.c_void_p(d_nbytes)))
+
+    # ---- host convenience ---------------------------------------------------------------------
+    def encode(self, images):
+        """images: float array [B,c,H,W] -> list of EncodingResult"""
+        images = np.ascontiguousarray(images, dtype=np.float64)
+        B = images.shape[0]
+        assert images.shape[1:] == (self.c, self.H, self.W)
+        ctx = self.ctx
+        d_img = DeviceArray(ctx, images.shape, np.float64)
+        d_out = DeviceArray(ctx, (B, self.slot_stride), np.uint8)
+        d_nbits = DeviceArray(ctx, (B,), np.uint64)
+        d_maxn = DeviceArray(ctx, (B,), np.uint8)
+        try:
+            d_img.upload(images)
+            self.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
+            ctx.synchronize()
+            out, nbits, maxn = d_out.download(), d_nbits.download(), d_maxn.download()
+        finally:
+            for d in (d_img, d_out, d_nbits, d_maxn):
+                d.free()
+        return [EncodingResult(out[b, :(int(nbits[b]) + 7) // 8].tobytes(), self.H, self.W, self.c, int(maxn[b]),
+                               self.level) for b in range(B)]
+
+    def decode(self, results):
+        """list of EncodingResult (same geometry) -> float64 [B,c,H',W']"""
+        B = len(results)
+        stride = max(4, (max(len(r.encoded_bytes) for r in results) + 3) & ~3)
+        data = np.zeros((B, stride), dtype=np.uint8)
+        for b, r in enumerate(results):
+            data[b, :len(r.encoded_bytes)] = np.frombuffer(r.encoded_bytes, np.uint8)
+        nbytes = np.array([len(r.encoded_bytes) for r in results], dtype=np.uint64)
+        maxn = np.array([r.max_n for r in results], dtype=np.uint8)
+        ctx = self.ctx
+        d_data = DeviceArray(ctx, data.shape, np.uint8)
+        d_nbytes = DeviceArray(ctx, (B,), np.uint64)
+        d_maxn = DeviceArray(ctx, (B,), np.uint8)
+        d_img = DeviceArray(ctx, (B, self.c, self.geom["rec_h"], self.geom["rec_w"]), np.float64)
+        try:
+            d_data.upload(data)
+            d_nbytes.upload(nbytes)
+            d_maxn.upload(maxn)
+            self.decode_device(d_data.ptr, d_nbytes.ptr, d_maxn.ptr, B, d_img.ptr, slot_stride=stride)
+            ctx.synchronize()
+            return d_img.download()
+        finally:
+            for d in (d_data, d_nbytes, d_maxn, d_img):
+                d.free()

@@ -20,6 +20,7 @@ int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxab
 int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
+int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
@@ -939,6 +940,15 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
                         d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
     }
     return read_err(ctx);
+}
+
+extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes) {
+    if (!ctx || !d_nbits || !d_nbytes || B < 0) return SPIHT_ERR_ARG;
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    LAUNCHCHK(spiht_launch_nbits_to_nbytes(d_nbits, (int)B, d_nbytes, ctx->stream));
+    return SPIHT_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

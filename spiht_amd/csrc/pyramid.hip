@@ -117,6 +117,15 @@ __global__ __launch_bounds__(256) void k_pyr_ll(PyrArgs a) {
     lm[i * w + j] = (uint8_t)lcode;
 }
 
+__global__ void k_nbits_to_nbytes(const uint64_t *nbits, int B, uint64_t *nbytes) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < B) nbytes[t] = (nbits[t] + 7) >> 3;
+}
+extern "C" int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_nbits_to_nbytes, dim3((B + 255) / 256), dim3(256), 0, st, d_nbits, B, d_nbytes);
+    return (int)hipGetLastError();
+}
+
 // ---- host launchers -------------------------------------------------------------------------
 
 extern "C" int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st) {
