@@ -32,8 +32,12 @@ struct TailOp {
     uint32_t kind; // 0 = write, 1 = refine
 };
 
+#define DEC_LIST 1024  // list entries staged in LDS per refill
+
 struct DecShared {
     uint32_t w[DEC_CH + 8];
+    uint32_t lst[DEC_LIST];
+    uint32_t seg[64];
     TailOp tail[DEC_TAIL];
 };
 
@@ -135,11 +139,16 @@ __device__ __forceinline__ uint64_t peek64(const DecShared &sh, const BitSrc &bs
     return s ? ((lo >> s) | ((uint64_t)hi << (64 - s))) : lo;
 }
 
-// Token-start mask of a LIP-pass window.  cin: bit 0 is the pending sign bit of the previous window's
-// last token.  cout: the token starting at bit 63 is '1' and its sign bit is the next window's bit 0.
-__device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t cin, uint32_t &cout) {
+// Token-start mask of a LIP-pass window (tokens '0' | '1 s').  The pass owns bits >= pos of the window.
+// cin: bit `pos` is the pending sign bit of the previous window's last token.  cout: the token starting at
+// bit 63 is '1' and its sign bit is the next window's bit 0.  Runs of ones pair up from their first bit, so
+// the sign positions are the odd offsets inside a run plus the zero that follows an odd-length run; the
+// run-parity is found with the add-carry trick used for escaped characters in SIMD JSON parsers.
+__device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t pos, uint32_t cin, uint32_t &cout) {
     const uint64_t E = 0x5555555555555555ull, O = 0xAAAAAAAAAAAAAAAAull;
-    uint64_t Wc = cin ? (W & ~1ull) : W;
+    const uint64_t own = ~0ull << pos;
+    uint64_t Wc = W & own;
+    if (cin) Wc &= ~(1ull << pos);
     uint64_t RS = Wc & ~(Wc << 1);               // first bit of every run of ones
     uint64_t ce = Wc + (RS & E);                 // carry ripples through runs starting on even bits
     uint64_t co = Wc + (RS & O);
@@ -147,10 +156,74 @@ __device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t cin, uint32_
     uint64_t Mo = Wc & ~Me;
     uint64_t G = (Me & O) | (Mo & E);            // odd offsets inside a run: sign bits
     G |= ((ce & ~Wc) & O) | ((co & ~Wc) & E);    // the zero right after an odd-length run: sign bit
-    if (cin) G |= 1ull;
-    uint64_t S = ~G;
+    if (cin) G |= 1ull << pos;
+    uint64_t S = ~G & own;
     cout = (uint32_t)((S >> 63) & (W >> 63) & 1ull);
     return S;
+}
+
+// popcount of the bits of `m` below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// 64 consecutive 64-bit stream words, one per lane, so that the serial passes fetch their windows with
+// v_readlane instead of a memory access
+struct RegChunk {
+    uint64_t v;
+    uint32_t base64;  // index of lane 0's 64-bit word
+    uint32_t valid;
+};
+
+// sequential reader of a list in global memory through an LDS stage of DEC_LIST entries
+struct ListRd {
+    const uint32_t *src;
+    uint32_t len, lo, hi;  // entries [lo,hi) are staged
+};
+
+__device__ __forceinline__ void regchunk_load(DecShared &sh, BitSrc &bs, RegChunk &rc, uint32_t base64, uint32_t lane) {
+    // words [2*base64, 2*base64+128) must be staged
+    uint32_t wfirst = 2 * base64;
+    if (wfirst < bs.cb || wfirst + 130 > bs.cb + DEC_CH + 8) refill(sh, bs, wfirst, lane);
+    uint32_t o = wfirst - bs.cb + 2 * lane;
+    rc.v = (uint64_t)sh.w[o] | ((uint64_t)sh.w[o + 1] << 32);
+    rc.base64 = base64;
+    rc.valid = 1;
+}
+
+// (lo, hi) = 64-bit stream words widx, widx+1
+__device__ __forceinline__ void window(DecShared &sh, BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane,
+                                       uint64_t &lo, uint64_t &hi) {
+    if (!rc.valid || widx < rc.base64 || widx + 1 >= rc.base64 + 64) regchunk_load(sh, bs, rc, widx, lane);
+    const uint32_t k = widx - rc.base64;
+    lo = readlane64(rc.v, k);
+    hi = readlane64(rc.v, k + 1);
+}
+
+__device__ __forceinline__ void list_stage(DecShared &sh, ListRd &r, uint32_t from, uint32_t lane) {
+    __syncthreads();
+    r.lo = from;
+    r.hi = (r.len - from) < (uint32_t)DEC_LIST ? r.len : from + DEC_LIST;
+    uint32_t v[DEC_LIST / 64];
+#pragma unroll
+    for (int u = 0; u < DEC_LIST / 64; u++) {
+        uint32_t t = from + (uint32_t)u * 64 + lane;
+        v[u] = t < r.hi ? r.src[t] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < DEC_LIST / 64; u++) sh.lst[u * 64 + lane] = v[u];
+    __syncthreads();
+}
+// make entries [a, min(a+64,len)) available in sh.lst at offset a - r.lo
+__device__ __forceinline__ void list_need(DecShared &sh, ListRd &r, uint32_t a, uint32_t lane) {
+    uint32_t b = (r.len - a) < 64u ? r.len : a + 64;
+    if (a < r.lo || b > r.hi) list_stage(sh, r, a, lane);
 }
 
 __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
@@ -159,7 +232,6 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
     const uint32_t lane = threadIdx.x;
     const uint32_t slot = blockIdx.x;
     const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
-    const uint64_t ltm = lt_mask(lane);
 
     uint32_t *lipA = a.lip0 + (size_t)slot * a.caps.lip;
     uint32_t *lipB = a.lip1 + (size_t)slot * a.caps.lip;
@@ -184,6 +256,8 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
         int n = (int)a.max_n[b];
         if (n > 30) { bad = true; n = 0; }
         refill(sh, bs, 0, lane);
+        RegChunk rc;
+        rc.v = 0; rc.base64 = 0; rc.valid = 0;
 
         uint32_t *lip = lipA, *lipn = lipB;
         uint32_t *lis = q0, *qa = q1, *qb = q2;
@@ -206,12 +280,13 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
             bool inlis = act && (((i | j) & 1u) != 0);
             uint64_t m = __ballot(inlis);
             if (act && t < a.caps.lip) lip[t] = idx;
-            uint32_t o = lis_len + (uint32_t)__popcll(m & ltm);
+            uint32_t o = lis_len + mbcnt(m);
             if (inlis && o < a.caps.lis) lis[o] = idx | ENT_A;
             lis_len += (uint32_t)__popcll(m);
         }
         lip_len = nroot;
         if (lip_len > a.caps.lip || lis_len > a.caps.lis) bad = true;
+        __syncthreads();
 
         bool done = bad;
         for (; !done; --n) {
@@ -220,42 +295,46 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
 
             // ---------------- LIP pass (encoder_decoder.rs:355-377) ----------------
             {
+                ListRd rd;
+                rd.src = lip; rd.len = lip_len; rd.lo = 0; rd.hi = 0;
                 uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0;
                 while (m_rem > 0 && !done) {
                     if (P >= nbits) { done = true; break; }
-                    ensure(sh, bs, P, 128, lane);
-                    const uint64_t Wd = uni64(peek64(sh, bs, P));
-                    const uint32_t nxtbit = uni32((uint32_t)(peek64(sh, bs, P + 64) & 1ull));
-                    const uint32_t vb = (nbits - P) < 64u ? (nbits - P) : 64u;
+                    const uint32_t widx = P >> 6, pos = P & 63u, Wb = widx << 6;
+                    uint64_t Wd, Wn;
+                    window(sh, bs, rc, widx, lane, Wd, Wn);
+                    const uint32_t nxtbit = (uint32_t)Wn & 1u;
+                    const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
                     uint32_t cout;
-                    uint64_t S = lip_starts(Wd, cin, cout);
+                    uint64_t S = lip_starts(Wd, pos, cin, cout);
                     if (vb < 64) S &= (1ull << vb) - 1ull;
                     const uint32_t cnt = (uint32_t)__popcll(S);
+                    list_need(sh, rd, tok_base, lane);
                     const bool isS = (S >> lane) & 1ull;
-                    const uint32_t rank = (uint32_t)__popcll(S & ltm);
+                    const uint32_t rank = mbcnt(S);
                     const bool inpass = isS && rank < m_rem;
                     const uint32_t sig = (uint32_t)(Wd >> lane) & 1u;
-                    const bool trunc = inpass && sig && (P + lane + 1 >= nbits);
+                    const bool trunc = inpass && sig && (Wb + lane + 1 >= nbits);
                     const bool valid = inpass && !trunc;
                     const uint32_t sgn = lane < 63 ? ((uint32_t)(Wd >> (lane + 1)) & 1u) : nxtbit;
-                    const uint32_t e = valid ? lip[tok_base + rank] : 0u;
+                    const uint32_t e = valid ? sh.lst[tok_base + rank - rd.lo] : 0u;
                     const uint64_t sigm = __ballot(valid && sig);
                     const uint64_t nsm = __ballot(valid && !sig);
                     const uint32_t nsig = (uint32_t)__popcll(sigm);
                     if (lsp_len + nsig > a.caps.lsp) { bad = true; done = true; break; }
-                    const bool istail = valid && sig && (P + lane + 1 >= tail_start);
+                    const bool istail = valid && sig && (Wb + lane + 1 >= tail_start);
                     const uint64_t tm = __ballot(istail);
                     if (valid && sig) {
-                        uint32_t t = lsp_len + (uint32_t)__popcll(sigm & ltm);
+                        uint32_t t = lsp_len + mbcnt(sigm);
                         int32_t v = sgn ? base_val : -base_val;
                         lsp_idx[t] = e;
                         lsp_val[t] = istail ? 0 : v;
                         if (istail) {
-                            uint32_t tp = ntail + (uint32_t)__popcll(tm & ltm);
+                            uint32_t tp = ntail + mbcnt(tm);
                             if (tp < DEC_TAIL) { sh.tail[tp].idx = e; sh.tail[tp].val = v; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 0; }
                         }
                     } else if (valid) {
-                        lipn[lipn_len + (uint32_t)__popcll(nsm & ltm)] = e;
+                        lipn[lipn_len + mbcnt(nsm)] = e;
                     }
                     ntail += (uint32_t)__popcll(tm);
                     lsp_len += nsig;
@@ -264,13 +343,13 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                     if (cnt > m_rem) {
                         // the pass ends inside this window, at the start of token number m_rem
                         uint64_t pm = __ballot(isS && rank == m_rem);
-                        P += (uint32_t)__builtin_ctzll(pm);
+                        P = Wb + (uint32_t)__builtin_ctzll(pm);
                         m_rem = 0;
                         cin = 0;
                     } else {
                         m_rem -= cnt;
                         tok_base += cnt;
-                        P += 64;
+                        P = Wb + 64;
                         cin = cout;
                     }
                 }
@@ -285,23 +364,32 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
             uint32_t cur_len = lis_len, ret_len = 0;
             while (cur_len > 0 && !done) {
                 uint32_t nxt_len = 0;
+                ListRd rd;
+                rd.src = cur; rd.len = cur_len; rd.lo = 0; rd.hi = 0;
                 for (uint32_t e0 = 0; e0 < cur_len && !done; e0 += 64) {
                     const uint32_t nE = (cur_len - e0) < 64u ? (cur_len - e0) : 64u;
                     const bool act = lane < nE;
-                    const uint32_t e = act ? cur[e0 + lane] : 0u;
+                    list_need(sh, rd, e0, lane);
+                    const uint32_t e = act ? sh.lst[e0 + lane - rd.lo] : 0u;
                     const uint32_t idx = e & ENT_IDX;
                     const bool isA = (e & ENT_A) != 0;
                     // only a type-A entry WITH offspring is followed by child bits when it fires
                     const bool leaf = (e & ENT_LEAF) != 0;
                     const uint64_t TA = __ballot(act && isA && !leaf);
-                    uint32_t mypos = POS_INVALID;
-                    ensure(sh, bs, P, 64 * 9 + 192, lane);  // whole window span staged: no refill during the walk
-                    // ---- position walk (uniform control flow) ----
-                    uint32_t i = 0;
-                    while (i < nE) {
-                        if (P >= nbits) break;
-                        const uint64_t lo = uni64(peek64(sh, bs, P));
-                        const uint64_t hi = uni64(peek64(sh, bs, P + 64));
+                    // the window's bits span at most 64*9 positions; stage them now so the walk and the
+                    // per-entry gathers below never trigger a refill in between
+                    // (a register-chunk reload wants 130 words past its base: cover that too)
+                    ensure(sh, bs, P, 64 * 9 + 130 * 32 + 256, lane);
+                    // ---- position walk (uniform control flow): hop from fired type-A entry to fired type-A entry;
+                    //      everything in between takes exactly one bit.  Each hop records a segment: entries
+                    //      [i, ...) sit at stream position delta + entry index ----
+                    uint64_t segmask = 0;
+                    uint32_t nseg = 0, i = 0;
+                    while (i < nE && P < nbits) {
+                        const uint32_t widx = P >> 6, Wb = widx << 6;
+                        uint32_t pos = P & 63u;
+                        uint64_t lo, hi;
+                        window(sh, bs, rc, widx, lane, lo, hi);
                         // length of a fired type-A entry starting at window position `lane`
                         uint32_t LAv;
                         {
@@ -316,32 +404,35 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                             }
                             LAv = 5 + ns;
                         }
-                        const uint32_t vb = (nbits - P) < 64u ? (nbits - P) : 64u;
-                        uint32_t pos = 0;
+                        const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
                         while (i < nE && pos < vb) {
-                            uint64_t cand = lo & ((TA >> i) << pos) & (~0ull << pos);
-                            const uint32_t lim = pos + (nE - i);
-                            if (lim < 64) cand &= (1ull << lim) - 1ull;
+                            const uint64_t cand = lo & ((TA >> i) << pos);  // TA has no bits at or past nE
+                            segmask |= 1ull << i;
+                            if (lane == 0) sh.seg[nseg] = Wb + pos - i;
+                            nseg++;
                             if (cand == 0) {
-                                uint32_t z = (vb - pos) < (nE - i) ? (vb - pos) : (nE - i);
-                                if (lane >= i && lane < i + z) mypos = P + pos + (lane - i);
+                                const uint32_t z = (vb - pos) < (nE - i) ? (vb - pos) : (nE - i);
                                 i += z;
                                 pos += z;
                             } else {
                                 const uint32_t f = (uint32_t)__builtin_ctzll(cand);
-                                const uint32_t z = f - pos;
-                                if (lane >= i && lane <= i + z) mypos = P + pos + (lane - i);
                                 const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)LAv, (int)f);
-                                i += z + 1;
+                                i += f - pos + 1;
                                 pos = f + len;
                             }
                         }
-                        P += pos;
+                        P = Wb + pos;
+                    }
+                    uint32_t mypos = POS_INVALID;
+                    {
+                        const uint32_t sidx = (uint32_t)__popcll(segmask & ((2ull << lane) - 1ull));
+                        const uint32_t dl = sh.seg[sidx ? sidx - 1 : 0];
+                        if (lane < i) mypos = dl + lane;
                     }
                     // ---- per-entry outputs ----
                     const bool have = act && mypos != POS_INVALID && mypos < nbits;
                     bool stop = act && !have;
-                    uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0, nT = 0;
+                    uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
                     uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
                     bool fired = false;
                     if (have) {
@@ -382,35 +473,44 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                                 }
                                 nLSP = (uint32_t)__popc(sigm);
                                 nLIP = (uint32_t)__popc(lipm);
-                                nT = (uint32_t)__popc(tailm);
                                 if (!stop) nQ = (4 * ii + 3 < H && 4 * jj + 3 < W) ? 1u : 0u;  // :411-414
                             }
                         }
                     }
-                    uint64_t pk = (uint64_t)nQ | ((uint64_t)nR << 12) | ((uint64_t)nLIP << 24) | ((uint64_t)nLSP << 36) |
-                                  ((uint64_t)nT << 48);
-                    uint64_t tot;
-                    uint64_t ex = wave_exscan(pk, tot, lane);
-                    const uint32_t tQ = (uint32_t)tot & 0xfffu, tR = (uint32_t)(tot >> 12) & 0xfffu;
-                    const uint32_t tLIP = (uint32_t)(tot >> 24) & 0xfffu, tLSP = (uint32_t)(tot >> 36) & 0xfffu;
-                    const uint32_t tT = (uint32_t)(tot >> 48) & 0xfffu;
+                    // exclusive prefix sums of the small per-lane counts, bit-sliced through ballots
+                    const uint64_t mR = __ballot(nR != 0);
+                    const uint64_t mQ1 = __ballot(nQ == 1), mQ4 = __ballot(nQ == 4);
+                    const uint64_t mS0 = __ballot(nLSP & 1u), mS1 = __ballot(nLSP & 2u), mS2 = __ballot(nLSP & 4u);
+                    const uint64_t mL0 = __ballot(nLIP & 1u), mL1 = __ballot(nLIP & 2u), mL2 = __ballot(nLIP & 4u);
+                    const uint32_t tR = (uint32_t)__popcll(mR);
+                    const uint32_t tQ = (uint32_t)__popcll(mQ1) + 4u * (uint32_t)__popcll(mQ4);
+                    const uint32_t tLSP = (uint32_t)__popcll(mS0) + 2u * (uint32_t)__popcll(mS1) + 4u * (uint32_t)__popcll(mS2);
+                    const uint32_t tLIP = (uint32_t)__popcll(mL0) + 2u * (uint32_t)__popcll(mL1) + 4u * (uint32_t)__popcll(mL2);
                     if (nxt_len + tQ > a.caps.lis || ret_len + tR > a.caps.lis || lip_len + tLIP > a.caps.lip ||
                         lsp_len + tLSP > a.caps.lsp) { bad = true; done = true; break; }
+                    const uint64_t mT = __ballot(tailm != 0);
+                    uint32_t exT = 0, tT = 0;
+                    if (mT) {  // rare: an entry consumed one of the last 8 bits
+                        uint64_t tot;
+                        uint64_t ex = wave_exscan((uint64_t)__popc(tailm), tot, lane);
+                        exT = (uint32_t)ex;
+                        tT = (uint32_t)tot;
+                    }
                     if (have) {
                         if (nR) {
-                            ret[ret_len + ((uint32_t)(ex >> 12) & 0xfffu)] = e;
+                            ret[ret_len + mbcnt(mR)] = e;
                         } else if (!fired) {
                             // fired leaf: dropped
                         } else if (!isA) {
-                            uint32_t oq = nxt_len + ((uint32_t)ex & 0xfffu);
+                            uint32_t oq = nxt_len + mbcnt(mQ1) + 4u * mbcnt(mQ4);
                             nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
                             nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
                             nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
                             nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
                         } else {
-                            uint32_t ol = lip_len + ((uint32_t)(ex >> 24) & 0xfffu);
-                            uint32_t os = lsp_len + ((uint32_t)(ex >> 36) & 0xfffu);
-                            uint32_t ot = ntail + ((uint32_t)(ex >> 48) & 0xfffu);
+                            uint32_t ol = lip_len + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
+                            uint32_t os = lsp_len + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
+                            uint32_t ot = ntail + exT;
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 uint32_t ci = cb + (q >> 1) * W + (q & 1);
@@ -428,13 +528,13 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                                     lip[ol++] = ci;
                                 }
                             }
-                            if (nQ) nxt[nxt_len + ((uint32_t)ex & 0xfffu)] = idx;  // type B
+                            if (nQ) nxt[nxt_len + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = idx;  // type B
                         }
                     }
                     nxt_len += tQ; ret_len += tR; lip_len += tLIP; lsp_len += tLSP; ntail += tT;
                     if (__ballot(stop)) done = true;
                 }
-                __syncthreads();  // entries of the next generation are read by other lanes
+                __syncthreads();  // entries of the next generation are read back through the LDS stage
                 { uint32_t *t = cur; cur = nxt; nxt = t; }
                 cur_len = nxt_len;
             }
@@ -446,22 +546,32 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
             {
                 const uint32_t left = nbits > P ? nbits - P : 0u;
                 const uint32_t count = lsp_len0 < left ? lsp_len0 : left;
-                for (uint32_t t0 = 0; t0 < count; t0 += 64) {
-                    ensure(sh, bs, P + t0, 64, lane);
-                    uint32_t t = t0 + lane;
-                    if (t < count) {
+                for (uint32_t t0 = 0; t0 < count; t0 += 256) {
+                    ensure(sh, bs, P + t0, 256 + 64, lane);
+                    int32_t v[4];
+                    uint32_t bit[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        uint32_t t = t0 + (uint32_t)u * 64 + lane;
+                        v[u] = t < count ? lsp_val[t] : 0;
                         uint32_t pos = P + t;
-                        uint32_t bit = (sh.w[(pos >> 5) - bs.cb] >> (pos & 31)) & 1u;
-                        bool tl = pos >= tail_start;
-                        if (!tl) lsp_val[t] = set_bit_i32(lsp_val[t], (uint32_t)n, bit);
-                        uint64_t tm = __ballot(tl);
-                        if (tl) {
-                            uint32_t tp = ntail + (uint32_t)__popcll(tm & ltm);
-                            if (tp < DEC_TAIL) { sh.tail[tp].idx = lsp_idx[t]; sh.tail[tp].val = (int32_t)bit; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 1; }
-                        }
-                        ntail += (uint32_t)__popcll(tm);
+                        bit[u] = t < count ? ((sh.w[(pos >> 5) - bs.cb] >> (pos & 31)) & 1u) : 0u;
                     }
-                    ntail = uni32(ntail);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        uint32_t t = t0 + (uint32_t)u * 64 + lane;
+                        const bool in = t < count;
+                        const bool tl = in && (P + t >= tail_start);
+                        if (in && !tl) lsp_val[t] = set_bit_i32(v[u], (uint32_t)n, bit[u]);
+                        const uint64_t tm = __ballot(tl);
+                        if (tm) {
+                            if (tl) {
+                                uint32_t tp = ntail + mbcnt(tm);
+                                if (tp < DEC_TAIL) { sh.tail[tp].idx = lsp_idx[t]; sh.tail[tp].val = (int32_t)bit[u]; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 1; }
+                            }
+                            ntail += (uint32_t)__popcll(tm);
+                        }
+                    }
                 }
                 P += count;
                 if (count < lsp_len0) { cut = count; done = true; }
