@@ -24,7 +24,9 @@ int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nby
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
-                             double q, hipStream_t st);
+                             double q, uint32_t *maxabs, hipStream_t st);
+int spiht_launch_zero_pads(int L, const int64_t *hs, const int64_t *ws, const int64_t *offh, const int64_t *offw, int enc_h,
+                           int enc_w, int32_t *coeffs, int planes, hipStream_t st);
 int spiht_launch_dequant_plain(const int32_t *in, double *out, size_t n_per_plane, int planes, int c,
                                const double *mults, double q, hipStream_t st);
 }
@@ -435,7 +437,7 @@ static int alloc_lists(spiht_ctx *ctx, const ListCaps &caps, int want_slots, boo
 
 // Encode B device-resident coefficient arrays.  max_bits already validated; queues work on ctx->stream.
 static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int B, uint64_t max_bits_in, uint8_t *d_out,
-                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn) {
+                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
     const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;  // encoder_decoder.rs:196
@@ -451,7 +453,7 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
         StageTimer t(ctx, ST_MEMSET);
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * slot_stride, ctx->stream));
     }
-    {
+    if (!have_maxabs) {
         StageTimer t(ctx, ST_ABSMAX);
         LAUNCHCHK(spiht_launch_absmax(d_x, B, g.n, (uint32_t *)ctx->maxabs.p, ctx->stream));
     }
@@ -735,18 +737,19 @@ static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, 
 
 // pixels [planes,H,W] -> quantised packed array [planes,enc_h,enc_w]
 static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
-                       double q, const double *d_mults, int32_t *d_coeffs) {
+                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr) {
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
     if (ig.L == 0) {
         StageTimer t(ctx, ST_DWT_REST);
-        LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, ctx->stream));
+        LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, d_maxabs, ctx->stream));
         return SPIHT_OK;
     }
     {
-        // zero padding cells of coeffs_to_array
+        // zero padding cells of coeffs_to_array (thin strips; every other cell is written by a band)
         StageTimer t(ctx, ST_MEMSET);
-        HIPCHK(hipMemsetAsync(d_coeffs, 0, plane_out * planes * 4, ctx->stream));
+        LAUNCHCHK(spiht_launch_zero_pads(ig.L, ig.hs, ig.ws, ig.offh, ig.offw, (int)ig.enc_h, (int)ig.enc_w, d_coeffs, planes,
+                                         ctx->stream));
     }
     if (ig.L >= 2) {
         CHK(ensure(ctx, ctx->a0, (size_t)planes * ig.hs[1] * ig.ws[1] * 8));
@@ -768,6 +771,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         a.ll_out = a.last ? nullptr : (double *)((l & 1) ? ctx->a0.p : ctx->a1.p);
         a.coeffs = d_coeffs;
         a.mults = d_mults;
+        a.maxabs = d_maxabs;
         a.q = q;
         memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
         memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
@@ -904,9 +908,12 @@ extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img,
             CHK(ensure(ctx, ctx->coeffs, (size_t)nb * g.n * 4));
             co = (int32_t *)ctx->coeffs.p;
         }
-        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co));
+        CHK(ensure(ctx, ctx->maxabs, (size_t)nb * 4));
+        HIPCHK(hipMemsetAsync(ctx->maxabs.p, 0, (size_t)nb * 4, ctx->stream));
+        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
+                        (uint32_t *)ctx->maxabs.p));
         CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
-                          d_max_n + b0));
+                          d_max_n + b0, true));
     }
     return read_err(ctx);
 }

@@ -105,10 +105,12 @@ struct DwtKArgs {
     int32_t in_h, in_w, out_h, out_w;
     int32_t off_h, off_w, enc_h, enc_w;
     int32_t last;          // coarsest level: LL is quantised into the packed array too
+    int32_t planes;        // B*c (set by the launcher)
     const double *in;      // [planes, in_h, in_w]
     double *ll_out;        // [planes, out_h, out_w]
     int32_t *coeffs;       // [planes, enc_h, enc_w]
     const double *mults;   // device [c] or null
+    uint32_t *maxabs;      // device [B] or null: atomicMax of |quantised coefficient| per image
     double q;
     double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // dec_lo, dec_hi
 };
@@ -122,6 +124,7 @@ struct IdwtKArgs {
     int32_t a_h, a_w;          // stored size of the incoming approximation (>= band; trim rule)
     int32_t off_h, off_w, enc_h, enc_w;
     int32_t first;             // coarsest level: approximation comes from rec[0:band_h, 0:band_w]
+    int32_t planes;            // B*c (set by the launcher)
     const double *a_in;        // [planes, a_h, a_w]
     const int32_t *rec;        // [planes, enc_h, enc_w]
     double *out;               // [planes, out_h, out_w]

@@ -5,24 +5,40 @@
 //   decode: rec/channel_mults -> dequantize -> array_to_coeffs -> waverec2       (spiht_wrapper.py:259-276)
 // One launch per decomposition level, both axes fused:
 //   forward: a workgroup owns a TH x TW tile of output positions of all four sub-bands.  The axis -2
-//            (row-direction) filter runs straight from global memory, one input column per thread with
-//            the column walked downwards so every input sample is loaded once per tile; the low/high
-//            intermediates go to LDS; the axis -1 filter reads them back and writes LL as float64 (input
-//            of the next level) and the three detail bands already quantised (int32, truncation toward
-//            zero) into their place in the zero-padded Mallat array -- coeffs_to_array and the two
-//            quantise passes of the wrapper cost no extra HBM traffic.
-//   inverse: the mirror image; detail bands are dequantised on load ((rec / m_k) / q as the wrapper
-//            does), axis -1 synthesis goes to LDS, axis -2 synthesis writes float64.
+//            filter runs straight from global memory: thread = input column, and the whole column segment
+//            the tile needs is loaded into registers FIRST (2*TH+F-2 independent 8-byte loads per lane in
+//            flight, consecutive lanes -> consecutive addresses), then filtered; the low/high intermediates
+//            go to LDS split by column parity so that the axis -1 filter reads them with unit stride.  LL
+//            is written as float64 (input of the next level); the three detail bands are written already
+//            quantised (int32, truncation toward zero) into their place in the zero-padded Mallat array --
+//            coeffs_to_array and the two quantise passes of the wrapper cost no extra HBM traffic -- and
+//            max|coefficient| (encoder_decoder.rs:165) is folded into the same pass.
+//   inverse: band tiles are dequantised on load ((rec / m_k) / q as the wrapper does) into LDS; thread =
+//            output column: axis -1 synthesis of one band row at a time feeds a register window of the
+//            last F/2 rows, from which the axis -2 synthesis emits two output rows -- no LDS round trip for
+//            the intermediate, stores are 512 B per wave.
 // Arithmetic follows the published pywt definitions in the same summation order as oracle/dwt_oracle.c
-// (ascending tap index, separate multiply and add: this file is compiled with -ffp-contract=off), so
-// GPU and oracle agree bit for bit and both agree with pywt to a few ulp.
-// HBM-bound: per level, reads 8 B per input sample, writes 8 B (LL) + 3*4 B (details) per output position.
+// (ascending tap / band index, separate multiply and add: this file is compiled with -ffp-contract=off),
+// so GPU and oracle agree bit for bit and both agree with pywt to a few ulp.
+// HBM-bound: per level, 8 B per input sample + 8 B (LL) + 3*4 B (details) per output position.
 #include "common.h"
 
 #define DW_TH 16      // output rows per tile
 #define DW_TW 64      // output cols per tile
 #define DW_BLOCK 256
 
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Remap the linear block id so
+// that each XCD walks one contiguous range of tiles: neighbouring tiles (shared halo columns/rows on the read
+// side, shared partial cache lines on the write side) then meet in the same L2.  Speed only, never correctness.
+__device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t &bx, uint32_t &by, uint32_t &bz) {
+    const uint32_t nt = gx * gy * gz, L = blockIdx.x;
+    const uint32_t q = nt >> 3, r = nt & 7u, x = L & 7u, j = L >> 3;
+    const uint32_t T = x * q + (x < r ? x : r) + j;
+    bx = T % gx;
+    const uint32_t t2 = T / gx;
+    by = t2 % gy;
+    bz = t2 / gy;
+}
 
 __device__ __forceinline__ int ext_index(int i, int N, int mode) {
     if (i >= 0 && i < N) return i;
@@ -52,48 +68,51 @@ __device__ __forceinline__ int32_t quant(double v, double m, double q, bool has_
     v = v * q;
     return (int32_t)v;
 }
+__device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 ? -x : x); }
 
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes)
 template <int F>
 __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
     constexpr int NR = 2 * DW_TH + F - 2;  // input rows needed
-    __shared__ double s_lo[DW_TH][NC + 1];
-    __shared__ double s_hi[DW_TH][NC + 1];
-    const int plane = blockIdx.z;
-    const int oh0 = blockIdx.y * DW_TH, ow0 = blockIdx.x * DW_TW;
-    const double *in = a.in + (size_t)plane * a.in_h * a.in_w;
+    constexpr int HC = (NC + 1) / 2;       // columns per parity plane
+    static_assert(NC <= DW_BLOCK, "one thread per input column");
+    __shared__ double s_lo[2][DW_TH][HC + 1];
+    __shared__ double s_hi[2][DW_TH][HC + 1];
+    __shared__ int s_row[NR];
+    uint32_t tbx, tby, tbz;
+    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+    const int plane = (int)tbz;
+    const int oh0 = (int)tby * DW_TH, ow0 = (int)tbx * DW_TW;
+    const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
     const int tid = threadIdx.x;
 
-    // ---- axis -2: thread <-> input column; sliding window down the rows ----
     // input row needed for output row o, tap j: 2*o + 1 - j ; first needed row r0 = 2*oh0 + 1 - (F-1)
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
-    for (int col = tid; col < NC; col += DW_BLOCK) {
-        const int gc = ext_index(c0 + col, a.in_w, a.mode);
-        double win[F];  // win[t] = x~[r0 + base + t]
+    if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
+    __syncthreads();
+
+    // ---- axis -2: thread <-> input column; all loads first, then the filter ----
+    if (tid < NC) {
+        const int gc = ext_index(c0 + tid, a.in_w, a.mode);
+        double x[NR];
 #pragma unroll
-        for (int t = 0; t < F - 2; t++) {
-            int gr = ext_index(r0 + t, a.in_h, a.mode);
-            win[t] = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
+        for (int r = 0; r < NR; r++) {
+            const int gr = s_row[r];
+            x[r] = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
         }
+        const int par = tid & 1, hc = tid >> 1;
 #pragma unroll
         for (int o = 0; o < DW_TH; o++) {
-            // rows r0 + 2o + F-2, r0 + 2o + F-1 enter the window
-            int gr1 = ext_index(r0 + 2 * o + F - 2, a.in_h, a.mode);
-            int gr2 = ext_index(r0 + 2 * o + F - 1, a.in_h, a.mode);
-            win[F - 2] = (gc < 0 || gr1 < 0) ? 0.0 : in[(size_t)gr1 * a.in_w + gc];
-            win[F - 1] = (gc < 0 || gr2 < 0) ? 0.0 : in[(size_t)gr2 * a.in_w + gc];
-            // out[o] = sum_j f[j] * x~[2(oh0+o)+1-j];  x~[2(oh0+o)+1-j] = win[F-1-j]
+            // out[o] = sum_j f[j] * x~[2(oh0+o)+1-j];  x~[2(oh0+o)+1-j] = x[2o + F-1-j]
             double sl = 0.0, shh = 0.0;
 #pragma unroll
             for (int j = 0; j < F; j++) {
-                sl += a.lo[j] * win[F - 1 - j];
-                shh += a.hi[j] * win[F - 1 - j];
+                sl += a.lo[j] * x[2 * o + F - 1 - j];
+                shh += a.hi[j] * x[2 * o + F - 1 - j];
             }
-            s_lo[o][col] = sl;
-            s_hi[o][col] = shh;
-#pragma unroll
-            for (int t = 0; t < F - 2; t++) win[t] = win[t + 2];
+            s_lo[par][o][hc] = sl;
+            s_hi[par][o][hc] = shh;
         }
     }
     __syncthreads();
@@ -102,39 +121,73 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     const int k = plane % a.c;
     const bool has_m = a.mults != nullptr;
     const double mk = has_m ? a.mults[k] : 1.0;
-    int32_t *co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
-    double *llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
-    for (int p = tid; p < DW_TH * DW_TW; p += DW_BLOCK) {
+    int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+    double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
+    uint32_t amax = 0;
+#pragma unroll
+    for (int u = 0; u < DW_TH * DW_TW / DW_BLOCK; u++) {
+        const int p = tid + u * DW_BLOCK;
         const int o = p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
         if (oh >= a.out_h || ow >= a.out_w) continue;
-        // x~ index 2*ow+1-j  ->  LDS column (2*ow+1-j) - c0 = 2*wcol + F-1 - j
+        // x~ index 2*ow+1-j  ->  tile column 2*wcol + F-1-j  ->  parity (F-1-j)&1, half-column wcol + (F-1-j)/2
         double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
 #pragma unroll
         for (int j = 0; j < F; j++) {
-            const double vl = s_lo[o][2 * wcol + F - 1 - j];
-            const double vh = s_hi[o][2 * wcol + F - 1 - j];
+            const double vl = s_lo[(F - 1 - j) & 1][o][wcol + ((F - 1 - j) >> 1)];
+            const double vh = s_hi[(F - 1 - j) & 1][o][wcol + ((F - 1 - j) >> 1)];
             aa += a.lo[j] * vl;
             ad += a.hi[j] * vl;
             da += a.lo[j] * vh;
             dd += a.hi[j] * vh;
         }
-        if (a.last) co[(size_t)oh * a.enc_w + ow] = quant(aa, mk, a.q, has_m);
-        else llo[(size_t)oh * a.out_w + ow] = aa;
-        co[(size_t)oh * a.enc_w + a.off_w + ow] = quant(ad, mk, a.q, has_m);                 // 'ad' top-right
-        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = quant(da, mk, a.q, has_m);               // 'da' bottom-left
-        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = quant(dd, mk, a.q, has_m);     // 'dd' bottom-right
+        const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        if (a.last) {
+            const int32_t qaa = quant(aa, mk, a.q, has_m);
+            co[(size_t)oh * a.enc_w + ow] = qaa;
+            amax = max(amax, iabs_u(qaa));
+        } else {
+            llo[(size_t)oh * a.out_w + ow] = aa;
+        }
+        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;                 // 'ad' top-right
+        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;               // 'da' bottom-left
+        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
+        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+
+// zero the padding cells of coeffs_to_array: per level the strip below 'ad' and the strip right of 'da'.
+// grid: (blocks, nrects, planes)
+struct PadRects {
+    int32_t n;
+    int32_t enc_h, enc_w, pad;
+    int32_t r0[2 * SPIHT_MAX_LEVELS], r1[2 * SPIHT_MAX_LEVELS], c0[2 * SPIHT_MAX_LEVELS], c1[2 * SPIHT_MAX_LEVELS];
+};
+__global__ __launch_bounds__(256) void k_zero_pads(PadRects pr, int32_t *coeffs) {
+    const int rc = blockIdx.y;
+    const int r0 = pr.r0[rc], r1 = pr.r1[rc], c0 = pr.c0[rc], c1 = pr.c1[rc];
+    const int w = c1 - c0, cells = (r1 - r0) * w;
+    int32_t *co = coeffs + (size_t)blockIdx.z * pr.enc_h * pr.enc_w;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < cells; t += gridDim.x * blockDim.x) {
+        int r = t / w, cidx = t - r * w;
+        co[(size_t)(r0 + r) * pr.enc_w + c0 + cidx] = 0;
     }
 }
 
 // level 0 of the API (no decomposition): quantise the image itself. grid-stride.
 __global__ __launch_bounds__(256) void k_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c,
-                                                     const double *mults, double q) {
+                                                     const double *mults, double q, uint32_t *maxabs) {
     size_t total = n_per_plane * (size_t)planes;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         int plane = (int)(t / n_per_plane);
         bool has_m = mults != nullptr;
-        out[t] = quant(in[t], has_m ? mults[plane % c] : 1.0, q, has_m);
+        int32_t v = quant(in[t], has_m ? mults[plane % c] : 1.0, q, has_m);
+        out[t] = v;
+        if (maxabs != nullptr && v != 0) atomicMax(&maxabs[plane / c], iabs_u(v));
     }
 }
 __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double *out, size_t n_per_plane, int planes, int c,
@@ -151,9 +204,8 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // ------------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------------
-#define IW_TH 32   // output rows per tile
-#define IW_TW 64   // output cols per tile
-
+#define IW_TH 32    // output rows per tile (two halves of 16, one per half of the workgroup)
+#define IW_TW 128   // output cols per tile, one thread per column per half
 
 __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
     double v = (double)r;
@@ -164,92 +216,106 @@ __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool ha
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes)
 template <int F>
 __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
-    // band indices k contributing to outputs n in [n0, n0+T): t = n+F-2-2k in [0,F)  ->
-    //   k >= (n0-1)/2 (ceil) ... k <= (n0+T-1+F-2)/2 (floor)
-    constexpr int KH = IW_TH / 2 + F / 2 + 1;   // band rows staged
-    constexpr int KW = IW_TW / 2 + F / 2 + 1;   // band cols staged
-    __shared__ double s_a[4][KH][KW + 1];       // aa, ad, da, dd (dequantised)
-    __shared__ double s_tl[KH][IW_TW + 1];
-    __shared__ double s_th[KH][IW_TW + 1];
-    const int plane = blockIdx.z;
+    // band index k contributes to output n with tap t = n + F - 2 - 2k in [0,F):  k in [n/2, n/2 + F/2 - 1]
+    constexpr int HF = F / 2;
+    constexpr int KH = IW_TH / 2 + HF - 1;   // band rows staged: outputs m0..m0+TH-1 need k in [m0/2, m0/2+TH/2-1+HF-1]
+    constexpr int KW = IW_TW / 2 + HF - 1;   // band cols staged
+    constexpr int KHH = IW_TH / 4 + HF - 1;  // band rows one half-tile walks
+    __shared__ double s_b[4][KH][KW + 1];    // aa, ad, da, dd (dequantised)
+    uint32_t tbx, tby, tbz;
+    xcd_tile((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IW_TH - 1) / IW_TH, a.planes, tbx, tby, tbz);
+    const int plane = (int)tbz;
     const int k = plane % a.c;
-    const int m0 = blockIdx.y * IW_TH, n0 = blockIdx.x * IW_TW;
-    const int kh0 = m0 > 0 ? (m0 - 1 + 1) / 2 : 0;  // ceil((m0-1)/2) for m0>=1; 0 for m0=0
-    const int kw0 = n0 > 0 ? (n0 - 1 + 1) / 2 : 0;
+    const int m0 = (int)tby * IW_TH, n0 = (int)tbx * IW_TW;
+    const int kh0 = m0 / 2, kw0 = n0 / 2;
     const bool has_m = a.mults != nullptr;
     const double mk = has_m ? a.mults[k] : 1.0;
-    const int32_t *rec = a.rec + (size_t)plane * a.enc_h * a.enc_w;
-    const double *ain = a.first ? nullptr : a.a_in + (size_t)plane * a.a_h * a.a_w;
+    const bool zero_ok = (!has_m || mk > 0.0) && a.q > 0.0;  // 0/m/q == +0.0 exactly: skip the divisions
+    const int32_t *__restrict__ rec = a.rec + (size_t)plane * a.enc_h * a.enc_w;
+    const double *__restrict__ ain = a.first ? nullptr : a.a_in + (size_t)plane * a.a_h * a.a_w;
     const int tid = threadIdx.x;
 
     for (int p = tid; p < KH * KW; p += DW_BLOCK) {
-        const int r = p / KW, cidx = p % KW;
+        const int r = p / KW, cidx = p - r * KW;
         const int bi = kh0 + r, bj = kw0 + cidx;
         double vaa = 0.0, vad = 0.0, vda = 0.0, vdd = 0.0;
         if (bi < a.band_h && bj < a.band_w) {
-            vaa = a.first ? dequant(rec[(size_t)bi * a.enc_w + bj], mk, a.q, has_m) : ain[(size_t)bi * a.a_w + bj];
-            vad = dequant(rec[(size_t)bi * a.enc_w + a.off_w + bj], mk, a.q, has_m);
-            vda = dequant(rec[(size_t)(a.off_h + bi) * a.enc_w + bj], mk, a.q, has_m);
-            vdd = dequant(rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj], mk, a.q, has_m);
+            const int32_t rad = rec[(size_t)bi * a.enc_w + a.off_w + bj];
+            const int32_t rda = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
+            const int32_t rdd = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            if (a.first) {
+                const int32_t raa = rec[(size_t)bi * a.enc_w + bj];
+                vaa = (raa == 0 && zero_ok) ? 0.0 : dequant(raa, mk, a.q, has_m);
+            } else {
+                vaa = ain[(size_t)bi * a.a_w + bj];
+            }
+            vad = (rad == 0 && zero_ok) ? 0.0 : dequant(rad, mk, a.q, has_m);
+            vda = (rda == 0 && zero_ok) ? 0.0 : dequant(rda, mk, a.q, has_m);
+            vdd = (rdd == 0 && zero_ok) ? 0.0 : dequant(rdd, mk, a.q, has_m);
         }
-        s_a[0][r][cidx] = vaa; s_a[1][r][cidx] = vad; s_a[2][r][cidx] = vda; s_a[3][r][cidx] = vdd;
+        s_b[0][r][cidx] = vaa; s_b[1][r][cidx] = vad; s_b[2][r][cidx] = vda; s_b[3][r][cidx] = vdd;
     }
     __syncthreads();
 
-    // ---- axis -1 synthesis: tl = idwt(aa, ad), th = idwt(da, dd) along columns ----
-    for (int p = tid; p < KH * IW_TW; p += DW_BLOCK) {
-        const int r = p / IW_TW, nn = p % IW_TW;
-        const int n = n0 + nn;
+    // thread = (output column nn, half): walks the band rows its 16 output rows need
+    const int nn = tid & (IW_TW - 1), half = tid / IW_TW;
+    const int n = n0 + nn;
+    const int np = n & 1;
+    const int cl = nn / 2;            // first contributing band column, tile-relative (= n/2 - kw0)
+    // taps along axis -1 for this column's parity: s = 0..HF-1  ->  t = np + F - 2 - 2s
+    double tlo[HF], thi[HF];
+#pragma unroll
+    for (int s = 0; s < HF; s++) {
+        tlo[s] = a.lo[np + F - 2 - 2 * s];
+        thi[s] = a.hi[np + F - 2 - 2 * s];
+    }
+    double wl[HF], wh[HF];  // register window: tl/th of the last HF band rows (index HF-1 = newest)
+#pragma unroll
+    for (int s = 0; s < HF; s++) { wl[s] = 0.0; wh[s] = 0.0; }
+    double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
+    const int rbase = half * (IW_TH / 4);  // first band row (tile-relative) of this half
+#pragma unroll
+    for (int rr = 0; rr < KHH; rr++) {
+        const int r = rbase + rr;
+        // axis -1 synthesis of band row r at output column n (ascending band column)
         double tl = 0.0, th = 0.0;
-        if (n < a.out_w && kh0 + r < a.band_h) {
-            // ascending band index kk with tap t = n + F - 2 - 2kk in [0, F)
-            int kk_lo = (n - 1 + 1) / 2;  // ceil((n-1)/2) for n >= 0
-            if (n == 0) kk_lo = 0;
-            for (int kk = kk_lo; kk < a.band_w; kk++) {
-                const int t = n + F - 2 - 2 * kk;
-                if (t < 0) break;
-                if (t >= F) continue;
-                const int lc = kk - kw0;
-                tl += s_a[0][r][lc] * a.lo[t] + s_a[1][r][lc] * a.hi[t];
-                th += s_a[2][r][lc] * a.lo[t] + s_a[3][r][lc] * a.hi[t];
+#pragma unroll
+        for (int s = 0; s < HF; s++) {
+            tl += s_b[0][r][cl + s] * tlo[s] + s_b[1][r][cl + s] * thi[s];
+            th += s_b[2][r][cl + s] * tlo[s] + s_b[3][r][cl + s] * thi[s];
+        }
+#pragma unroll
+        for (int s = 0; s < HF - 1; s++) { wl[s] = wl[s + 1]; wh[s] = wh[s + 1]; }
+        wl[HF - 1] = tl;
+        wh[HF - 1] = th;
+        if (rr >= HF - 1) {
+            // window holds band rows kb..kb+HF-1 with kb = kh0 + r - (HF-1): output rows 2kb, 2kb+1
+            const int m = 2 * (kh0 + r - (HF - 1));
+#pragma unroll
+            for (int mp = 0; mp < 2; mp++) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int s = 0; s < HF; s++) sacc += wl[s] * a.lo[mp + F - 2 - 2 * s] + wh[s] * a.hi[mp + F - 2 - 2 * s];
+                if (m + mp < a.out_h && n < a.out_w) out[(size_t)(m + mp) * a.out_w + n] = sacc;
             }
         }
-        s_tl[r][nn] = tl;
-        s_th[r][nn] = th;
-    }
-    __syncthreads();
-
-    // ---- axis -2 synthesis ----
-    double *out = a.out + (size_t)plane * a.out_h * a.out_w;
-    for (int p = tid; p < IW_TH * IW_TW; p += DW_BLOCK) {
-        const int mm = p / IW_TW, nn = p % IW_TW;
-        const int m = m0 + mm, n = n0 + nn;
-        if (m >= a.out_h || n >= a.out_w) continue;
-        double s = 0.0;
-        int kk_lo = (m == 0) ? 0 : m / 2;  // ceil((m-1)/2)
-        for (int kk = kk_lo; kk < a.band_h; kk++) {
-            const int t = m + F - 2 - 2 * kk;
-            if (t < 0) break;
-            if (t >= F) continue;
-            const int lr = kk - kh0;
-            s += s_tl[lr][nn] * a.lo[t] + s_th[lr][nn] * a.hi[t];
-        }
-        out[(size_t)m * a.out_w + n] = s;
     }
 }
 
 // ---- host launchers -----------------------------------------------------------------------------
 
 template <int F>
-static int launch_dwt_F(const DwtKArgs &a, int planes, hipStream_t st) {
-    dim3 grid((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, planes);
-    hipLaunchKernelGGL(k_dwt_level<F>, grid, dim3(DW_BLOCK), 0, st, a);
+static int launch_dwt_F(DwtKArgs a, int planes, hipStream_t st) {
+    a.planes = planes;
+    uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+    hipLaunchKernelGGL(k_dwt_level<F>, dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
 }
 template <int F>
-static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st) {
-    dim3 grid((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IW_TH - 1) / IW_TH, planes);
-    hipLaunchKernelGGL(k_idwt_level<F>, grid, dim3(DW_BLOCK), 0, st, a);
+static int launch_idwt_F(IdwtKArgs a, int planes, hipStream_t st) {
+    a.planes = planes;
+    uint32_t nt = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW) * (uint32_t)((a.out_h + IW_TH - 1) / IW_TH) * (uint32_t)planes;
+    hipLaunchKernelGGL(k_idwt_level<F>, dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
 }
 
@@ -271,9 +337,28 @@ extern "C" int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream
     default: return -1;
     }
 }
+// pad strips of coeffs_to_array for `L` levels: hs/ws band sizes and offh/offw block offsets (index 1..L)
+extern "C" int spiht_launch_zero_pads(int L, const int64_t *hs, const int64_t *ws, const int64_t *offh, const int64_t *offw,
+                                      int enc_h, int enc_w, int32_t *coeffs, int planes, hipStream_t st) {
+    PadRects pr;
+    pr.n = 0; pr.enc_h = enc_h; pr.enc_w = enc_w; pr.pad = 0;
+    for (int l = 1; l <= L; l++) {
+        if (offh[l] > hs[l]) {  // below 'ad'
+            pr.r0[pr.n] = (int)hs[l]; pr.r1[pr.n] = (int)offh[l]; pr.c0[pr.n] = (int)offw[l]; pr.c1[pr.n] = (int)(offw[l] + ws[l]);
+            pr.n++;
+        }
+        if (offw[l] > ws[l]) {  // right of 'da'
+            pr.r0[pr.n] = (int)offh[l]; pr.r1[pr.n] = (int)(offh[l] + hs[l]); pr.c0[pr.n] = (int)ws[l]; pr.c1[pr.n] = (int)offw[l];
+            pr.n++;
+        }
+    }
+    if (pr.n == 0) return 0;
+    hipLaunchKernelGGL(k_zero_pads, dim3(8, pr.n, planes), dim3(256), 0, st, pr, coeffs);
+    return (int)hipGetLastError();
+}
 extern "C" int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c,
-                                        const double *mults, double q, hipStream_t st) {
-    hipLaunchKernelGGL(k_quant_plain, dim3(1024), dim3(256), 0, st, in, out, n_per_plane, planes, c, mults, q);
+                                        const double *mults, double q, uint32_t *maxabs, hipStream_t st) {
+    hipLaunchKernelGGL(k_quant_plain, dim3(1024), dim3(256), 0, st, in, out, n_per_plane, planes, c, mults, q, maxabs);
     return (int)hipGetLastError();
 }
 extern "C" int spiht_launch_dequant_plain(const int32_t *in, double *out, size_t n_per_plane, int planes, int c,
