@@ -49,41 +49,85 @@ __global__ __launch_bounds__(256) void k_absmax(const int32_t *__restrict__ x, u
     }
 }
 
-// One index-doubling round.  grid: (ceil(gj/64), ceil(gi/4), B*c), block (64,4).
-__global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a) {
+// 4-byte-aligned vector types: gfx950 runs in unaligned-access mode, so these become one dwordx4 / dwordx2 /
+// dword / short access even though rows of an odd-width array start on arbitrary 4-byte (1-byte) boundaries
+struct __attribute__((packed, aligned(4))) i4u { int32_t v[4]; };
+struct __attribute__((packed, aligned(4))) i2u { int32_t v[2]; };
+struct __attribute__((packed, aligned(1))) b4u { uint8_t v[4]; };
+struct __attribute__((packed, aligned(1))) b2u { uint8_t v[2]; };
+
+// One index-doubling round: thread = two horizontally adjacent parents (i, 2t), (i, 2t+1): their 2x4 block of
+// children is read with one 16-byte load per child row.  1-D grid, XCD-contiguous tile order.
+// tiles: (ceil(npairs/64), ceil(gi/4), B*c), block (64,4).
+__global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a, uint32_t gx, uint32_t gy, uint32_t gz) {
     const Geom g = a.g;
     const int d = a.round;
-    const uint32_t j = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t i = blockIdx.y * 4 + threadIdx.y;
-    const uint32_t bk = blockIdx.z;  // b*c + k
-    const uint32_t h = (uint32_t)g.h, w = (uint32_t)g.w;
-    // depth >= d ?
-    if ((uint64_t)i * (1ull << d) + 1 >= h || (uint64_t)j * (1ull << d) + 1 >= w) return;
-    // depth >= d+1 -> a later round
-    if ((uint64_t)i * (2ull << d) + 1 < h && (uint64_t)j * (2ull << d) + 1 < w) return;
-    // root-block nodes use the remap rule (k_pyr_ll)
-    if (i < (uint32_t)g.ll_h && j < (uint32_t)g.ll_w) return;
-    const size_t base = (size_t)bk * g.hw;
-    const int32_t *x = a.x + base;
-    uint8_t *dm = a.dmsb + base;
-    uint8_t *lm = a.lmsb + base;
-    const uint32_t ci = 2 * i, cj = 2 * j;
-    const uint32_t c0 = ci * w + cj;
-    uint32_t dcode = 0, lcode = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        uint32_t oi = ci + (q >> 1), oj = cj + (q & 1);
-        uint32_t o = c0 + (q >> 1) * w + (q & 1);
-        uint32_t s = msb_code(iabs_u(x[o]));
-        if (d > 1 && 2 * oi + 1 < h && 2 * oj + 1 < w) {
-            uint32_t dc = dm[o];
-            s = max(s, dc);
-            lcode = max(lcode, dc);
-        }
-        dcode = max(dcode, s);
+    uint32_t bx, by, bz;
+    {
+        const uint32_t nt = gx * gy * gz, L = blockIdx.x;
+        const uint32_t q = nt >> 3, r = nt & 7u, x = L & 7u, jj = L >> 3;
+        const uint32_t T = x * q + (x < r ? x : r) + jj;
+        bx = T % gx;
+        const uint32_t t2 = T / gx;
+        by = t2 % gy;
+        bz = t2 / gy;
     }
-    dm[i * w + j] = (uint8_t)dcode;
-    lm[i * w + j] = (uint8_t)lcode;
+    const uint32_t t = bx * 64 + threadIdx.x;   // parent pair
+    const uint32_t i = by * 4 + threadIdx.y;
+    const uint32_t h = (uint32_t)g.h, w = (uint32_t)g.w;
+    const uint64_t s1 = 1ull << d, s2 = 2ull << d;
+    if ((uint64_t)i * s1 + 1 >= h) return;
+    const uint32_t j0 = 2 * t, j1 = 2 * t + 1;
+    // depth exactly d, and not a root-block node (k_pyr_ll handles those)
+    bool v0 = (uint64_t)j0 * s1 + 1 < w && !((uint64_t)i * s2 + 1 < h && (uint64_t)j0 * s2 + 1 < w) &&
+              !(i < (uint32_t)g.ll_h && j0 < (uint32_t)g.ll_w);
+    bool v1 = (uint64_t)j1 * s1 + 1 < w && !((uint64_t)i * s2 + 1 < h && (uint64_t)j1 * s2 + 1 < w) &&
+              !(i < (uint32_t)g.ll_h && j1 < (uint32_t)g.ll_w);
+    if (!v0 && !v1) return;
+    const size_t base = (size_t)bz * g.hw;
+    const int32_t *__restrict__ x = a.x + base;
+    uint8_t *__restrict__ dm = a.dmsb + base;
+    uint8_t *__restrict__ lm = a.lmsb + base;
+    const uint32_t ci = 2 * i, cj = 4 * t;
+    const uint32_t c0 = ci * w + cj;
+    int32_t xv[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint8_t dv[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const bool wide = cj + 3 < w;  // both parents' children exist as columns
+    if (wide) {
+        i4u r0 = *reinterpret_cast<const i4u *>(x + c0), r1 = *reinterpret_cast<const i4u *>(x + c0 + w);
+#pragma unroll
+        for (int q = 0; q < 4; q++) { xv[0][q] = r0.v[q]; xv[1][q] = r1.v[q]; }
+        if (d > 1) {
+            b4u e0 = *reinterpret_cast<const b4u *>(dm + c0), e1 = *reinterpret_cast<const b4u *>(dm + c0 + w);
+#pragma unroll
+            for (int q = 0; q < 4; q++) { dv[0][q] = e0.v[q]; dv[1][q] = e1.v[q]; }
+        }
+    } else {
+        i2u r0 = *reinterpret_cast<const i2u *>(x + c0), r1 = *reinterpret_cast<const i2u *>(x + c0 + w);
+        xv[0][0] = r0.v[0]; xv[0][1] = r0.v[1]; xv[1][0] = r1.v[0]; xv[1][1] = r1.v[1];
+        if (d > 1) {
+            b2u e0 = *reinterpret_cast<const b2u *>(dm + c0), e1 = *reinterpret_cast<const b2u *>(dm + c0 + w);
+            dv[0][0] = e0.v[0]; dv[0][1] = e0.v[1]; dv[1][0] = e1.v[0]; dv[1][1] = e1.v[1];
+        }
+    }
+    uint32_t dcode[2] = {0, 0}, lcode[2] = {0, 0};
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int rr = q >> 1, cc = 2 * pr + (q & 1);
+            const uint32_t oi = ci + rr, oj = cj + cc;
+            uint32_t s = msb_code(iabs_u(xv[rr][cc]));
+            if (d > 1 && 2 * oi + 1 < h && 2 * oj + 1 < w) {
+                const uint32_t dc = dv[rr][cc];
+                s = max(s, dc);
+                lcode[pr] = max(lcode[pr], dc);
+            }
+            dcode[pr] = max(dcode[pr], s);
+        }
+    }
+    if (v0) { dm[i * w + j0] = (uint8_t)dcode[0]; lm[i * w + j0] = (uint8_t)lcode[0]; }
+    if (v1) { dm[i * w + j1] = (uint8_t)dcode[1]; lm[i * w + j1] = (uint8_t)lcode[1]; }
 }
 
 // Root block (encoder_decoder.rs:44-63).  grid: (ceil(ll_w*ll_h/256), 1, B*c)
@@ -165,8 +209,9 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
         uint32_t gi = (uint32_t)(((uint64_t)g->h - 1 + (1ull << d) - 1) >> d);
         uint32_t gj = (uint32_t)(((uint64_t)g->w - 1 + (1ull << d) - 1) >> d);
         if (gi == 0 || gj == 0) continue;
-        dim3 grid((gj + 63) / 64, (gi + 3) / 4, (uint32_t)(B * g->c));
-        hipLaunchKernelGGL(k_pyr_round, grid, dim3(64, 4), 0, st, a);
+        const uint32_t npairs = (gj + 1) / 2;
+        const uint32_t gx = (npairs + 63) / 64, gy = (gi + 3) / 4, gz = (uint32_t)(B * g->c);
+        hipLaunchKernelGGL(k_pyr_round, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
     }
     a.round = 0;
     dim3 grid((uint32_t)((g->ll_h * g->ll_w + 255) / 256), 1, (uint32_t)(B * g->c));
