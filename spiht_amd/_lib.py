@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspiht_hip.so")
+LIB_PATH = os.environ.get("SPIHT_HIP_LIB") or os.path.join(_HERE, "libspiht_hip.so")  # override: diagnostic builds
 
 OK, ERR_LL, ERR_EMPTY, ERR_SHAPE, ERR_CAPACITY, ERR_HIP, ERR_ARG, ERR_MAGNITUDE, ERR_INTERNAL, ERR_TOO_LARGE, \
     ERR_NOMEM = range(11)
@@ -107,7 +107,7 @@ def check(status):
     if status == ERR_HIP:
         raise SpihtHipError("%s: %s" % (msg, L.spiht_last_hip_error().decode()))
     if status in (ERR_INTERNAL, ERR_NOMEM):
-        raise SpihtHipError(msg)
+        raise SpihtHipError("%s (%s)" % (msg, L.spiht_last_hip_error().decode()))
     if status == ERR_TOO_LARGE:
         raise OverflowError(msg)
     raise ValueError(msg)

@@ -396,7 +396,10 @@ static int read_err(spiht_ctx *ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (e & 2u) return SPIHT_ERR_MAGNITUDE;
     if (e & 4u) return SPIHT_ERR_CAPACITY;
-    if (e & 1u) return SPIHT_ERR_INTERNAL;
+    if (e & 1u) {
+        g_hip_err = "device error word 0x" + [](uint32_t v) { char b[16]; snprintf(b, sizeof b, "%x", v); return std::string(b); }(e);
+        return SPIHT_ERR_INTERNAL;
+    }
     return SPIHT_OK;
 }
 
@@ -955,6 +958,15 @@ extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, in
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     LAUNCHCHK(spiht_launch_nbits_to_nbytes(d_nbits, (int)B, d_nbytes, ctx->stream));
+    return SPIHT_OK;
+}
+
+// diagnostic: copy the device error/debug words (64 x uint32) to the host
+extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
+    if (!ctx || !out64) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out64, ctx->err.p, 256, hipMemcpyDeviceToHost));
     return SPIHT_OK;
 }
 

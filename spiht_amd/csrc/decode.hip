@@ -1,73 +1,111 @@
-// SPIHT list decoder (gfx950): one wavefront owns one image at a time.
+// SPIHT list decoder (gfx950): one workgroup of DEC_NW wavefronts owns one image at a time.
 //
 // Reproduces /root/reference/src/encoder_decoder.rs:307-454 on all 8*nbytes bits of the stream
-// (src/lib.rs:38 hands the pad bits to the decoder as data).  Unlike the encoder, the position of a
-// list entry's bits depends on every bit decoded before it, so the three passes are attacked
-// differently:
-//   * LIP pass: tokens are '0' | '1 s'.  For a 64-bit window the token-start mask is computed in O(1)
-//     with the carry trick used for escaped characters in SIMD JSON parsers (runs of ones pair up from
-//     their first bit); lane l then owns stream position l, its token rank is a popcount, and LIP
-//     reads / LSP+LIP writes are coalesced.
-//   * LIS pass: per generation, windows of 64 entries.  Unfired entries and fired B entries take one
-//     bit; only a fired A entry (1 + 4..8 bits) shifts what follows.  Lane l precomputes the length a
-//     fired A entry would have at stream position l; a scalar walk then hops from fired A to fired A
-//     (find-first-set on `bits & type-mask`), assigning every entry its position.  Outputs (next
-//     generation, retained list, LIP/LSP appends) are then produced in parallel with one packed
-//     wave scan.
-//   * refinement: bit t belongs to LSP entry t.
-// Decoded magnitudes live next to the LSP (lsp_val) and are scattered into the coefficient array
-// at the end; the few operations that consumed one of the last 8 bits of the stream (possible pad
-// bits, Q9) are replayed serially in list order so duplicated tree nodes (Q4) end exactly as the
-// reference's sequential writes leave them.
+// (src/lib.rs:38 hands the pad bits to the decoder as data).  Unlike the encoder, the position of a list
+// entry's bits depends on every bit decoded before it.  What is truly serial is only WHERE each entry's bits
+// start; everything else (values, list appends) is data parallel once that is known.  So wavefront 0 is a
+// sequencer that only finds boundaries, one 64-bit stream window at a time, and hands each window to one of
+// the worker wavefronts through an LDS ring:
+//   * LIP pass: tokens are '0' | '1 s'.  The token-start mask of a window is computed in O(1) with the carry
+//     trick used for escaped characters in SIMD JSON parsers (runs of ones pair up from their first bit), so
+//     the sequencer knows token, LSP and LIP counts of the window from popcounts and gives the worker exact
+//     list offsets.
+//   * LIS pass (generation by generation = the reference's FIFO order): unfired entries and fired B entries
+//     take one bit; only a fired type-A entry (1 + 4..8 bits) shifts what follows.  Lane l precomputes the
+//     length a fired A entry would have at window position l; a scalar walk hops from fired A to fired A
+//     (find-first-set on `bits & type-mask`) and records their positions.  The worker rebuilds entry starts from
+//     that mask, lane = stream position, and produces next generation / retained list / LIP / LSP appends; the
+//     running list lengths pass from worker to worker through a small LDS chain.
+//   * refinement: bit t belongs to LSP entry t -- all wavefronts, no sequencing.
+// Decoded magnitudes live next to the LSP (lsp_val) and are scattered into the coefficient array at the end;
+// the few operations that consumed one of the last 8 bits of the stream (possible pad bits, Q9) are replayed
+// serially in stream order so duplicated tree nodes (Q4) end exactly as the reference's sequential writes
+// leave them.
 #include "common.h"
 
-#define DEC_CH 2048  // 32-bit words of stream staged in LDS per wave
+#ifndef DEC_NW
+#define DEC_NW 8            // wavefronts per workgroup: 1 sequencer + (DEC_NW-1) workers
+#endif
+#define DEC_NWK (DEC_NW - 1)
+#define DEC_RING (4 * DEC_NW)  // windows in flight between sequencer and workers
 #define DEC_TAIL 16
-#define POS_INVALID 0xFFFFFFFFu
+#define SEQ_OPEN 0xFFFFFFFFu
+#define SPIN_LIMIT (1u << 24)  // bound on every LDS spin (about a second): a protocol bug must not hang the GPU
+
+#ifdef DEC_PROF  // diagnostic build only: where the sequencer's time goes (s_memtime ticks >> 10 into err[16..])
+#define PF_ADD(k) do { uint64_t _n = __builtin_amdgcn_s_memtime(); pf[k] += _n - pt; pt = _n; } while (0)
+#define PF_CNT(k, v) pf[k] += (v)
+#else
+#define PF_ADD(k)
+#define PF_CNT(k, v)
+#endif
 
 struct TailOp {
+    uint32_t key;  // stream position of the deciding bit (replay order)
     uint32_t idx;
     int32_t val;   // value for a write, bit for a refine
-    uint32_t n;    // plane
-    uint32_t kind; // 0 = write, 1 = refine
+    uint32_t n;    // plane; bit 31 set: refine, clear: write
 };
 
-#define DEC_LIST 1024  // list entries staged in LDS per refill
+struct Item {  // one 64-bit stream window of one pass
+    uint32_t kind;        // 0 = LIP window, 1 = LIS window
+    uint32_t Wb;          // stream position of window bit 0
+    uint32_t pos0, pos1;  // the pass owns window bits [pos0, pos1)
+    uint32_t e_start;     // LIP: index in the LIP of the first token; LIS: index in the queue of the first entry
+    uint32_t cin;         // LIP: bit pos0 is the pending sign bit of the previous window's last token
+    uint32_t m_rem;       // LIP: tokens still to read at window start
+    uint32_t first;       // LIS: first window of the generation -> bases below instead of the chain
+    uint32_t b_lsp, b_lip, b_nxt, b_ret;  // list lengths before this window (LIP pass: exact, from the sequencer)
+    uint64_t lo, hi;      // window bits and the next window's bits (zero at and past nbits)
+    uint64_t fm;          // LIS: start positions of fired type-A entries with offspring
+};
+
+// LDS form of an item: 12 payload words (three 16-byte writes by one lane) + the `ready` word, which is written
+// LAST and holds sequence number + 1.
+struct __attribute__((aligned(16))) Slot {
+    uint32_t w0;         // kind | pos0 << 8 | pos1 << 16 | cin << 24 | first << 25
+    uint32_t Wb, e_start;
+    uint32_t m_rem;       // LIP: m_rem;  LIS: b_ret
+    uint32_t b_lsp, b_lip;
+    uint32_t lo0, lo1, hi0, hi1, fm0, fm1;
+    uint32_t ready;
+    uint32_t pad[3];
+};
+
+struct Chain {  // running list lengths after item k; seq == k+1 once item k published them
+    uint32_t seq;
+    uint32_t lsp, lip, nxt, ret;
+};
 
 struct DecShared {
-    uint32_t w[DEC_CH + 8];
-    uint32_t lst[DEC_LIST];
-    uint32_t seg[64];
+    Slot ring[DEC_RING];
+    Chain chain[DEC_RING];
+    uint32_t head;              // items produced so far
+    uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
+    uint32_t wdone[DEC_NWK];    // items completed per worker
+    uint32_t ntail;
+    uint32_t bad;
+    // results of a phase, written by the sequencer before the closing barrier
+    uint32_t r_P, r_done, r_lsp, r_lip;
     TailOp tail[DEC_TAIL];
 };
 
-__device__ __forceinline__ uint64_t lt_mask(uint32_t lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
-
-__device__ __forceinline__ uint64_t uni64(uint64_t v) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
+__device__ __forceinline__ uint32_t lds_load(uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = (uint32_t)__shfl_up((int)lo, o);
-    hi = (uint32_t)__shfl_up((int)hi, o);
-    return ((uint64_t)hi << 32) | lo;
+__device__ __forceinline__ void lds_store(uint32_t *p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-__device__ __forceinline__ uint64_t wave_exscan(uint64_t v, uint64_t &total, uint32_t lane) {
-    uint64_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        uint64_t t = shfl_up_u64(inc, o);
-        if (lane >= (uint32_t)o) inc += t;
-    }
-    uint32_t lo = (uint32_t)__shfl((int)(uint32_t)inc, 63);
-    uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(inc >> 32), 63);
-    total = ((uint64_t)hi << 32) | lo;
-    return inc - v;
+// popcount of the bits of `m` below this lane
+__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
+    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
+    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // encoder_decoder.rs:14-29
@@ -101,49 +139,11 @@ __device__ __forceinline__ uint32_t make_a_entry(uint32_t idx, uint32_t ci, uint
     return idx | ENT_A | ((2 * ci + 1 < H && 2 * cj + 1 < W) ? 0u : ENT_LEAF);
 }
 
-struct BitSrc {
-    const uint32_t *gw;   // stream words of this image
-    uint32_t nwords;      // words readable in the slot
-    uint32_t nbits;       // valid bits (8*nbytes)
-    uint32_t cb;          // first word staged in LDS
-};
-
-// stage words [wbase, wbase+DEC_CH+8) with everything at or past nbits forced to zero
-__device__ __forceinline__ void refill(DecShared &sh, BitSrc &bs, uint32_t wbase, uint32_t lane) {
-    __syncthreads();
-    bs.cb = wbase;
-    for (uint32_t t = lane; t < DEC_CH + 8; t += 64) {
-        uint32_t wi = wbase + t;
-        uint32_t v = 0;
-        uint64_t b0 = (uint64_t)wi * 32;
-        if (wi < bs.nwords && b0 < bs.nbits) {
-            v = bs.gw[wi];
-            uint32_t rem = bs.nbits - (uint32_t)b0;
-            if (rem < 32) v &= (1u << rem) - 1u;
-        }
-        sh.w[t] = v;
-    }
-    __syncthreads();
-}
-
-// make sure bits [P, P+need) (+64 of slack for peek64) are staged; P never decreases
-__device__ __forceinline__ void ensure(DecShared &sh, BitSrc &bs, uint32_t P, uint32_t need, uint32_t lane) {
-    uint32_t lastw = (uint32_t)(((uint64_t)P + need + 63) >> 5) + 2;
-    if (lastw >= bs.cb + DEC_CH + 8 || (P >> 5) < bs.cb) refill(sh, bs, P >> 5, lane);
-}
-
-__device__ __forceinline__ uint64_t peek64(const DecShared &sh, const BitSrc &bs, uint32_t pos) {
-    uint32_t w = (pos >> 5) - bs.cb, s = pos & 31;
-    uint64_t lo = (uint64_t)sh.w[w] | ((uint64_t)sh.w[w + 1] << 32);
-    uint32_t hi = sh.w[w + 2];
-    return s ? ((lo >> s) | ((uint64_t)hi << (64 - s))) : lo;
-}
-
 // Token-start mask of a LIP-pass window (tokens '0' | '1 s').  The pass owns bits >= pos of the window.
 // cin: bit `pos` is the pending sign bit of the previous window's last token.  cout: the token starting at
 // bit 63 is '1' and its sign bit is the next window's bit 0.  Runs of ones pair up from their first bit, so
 // the sign positions are the odd offsets inside a run plus the zero that follows an odd-length run; the
-// run-parity is found with the add-carry trick used for escaped characters in SIMD JSON parsers.
+// run-parity is found with the add-carry trick.
 __device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t pos, uint32_t cin, uint32_t &cout) {
     const uint64_t E = 0x5555555555555555ull, O = 0xAAAAAAAAAAAAAAAAull;
     const uint64_t own = ~0ull << pos;
@@ -162,76 +162,348 @@ __device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t pos, uint32_
     return S;
 }
 
-// popcount of the bits of `m` below this lane
-__device__ __forceinline__ uint32_t mbcnt(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+// What a LIP window contains, as a function of the item fields only: sequencer and worker both call it.
+struct LipWin {
+    uint64_t S_in;     // token starts that belong to the pass and are complete
+    uint64_t sig;      // those of them that are significant ('1 s')
+    uint32_t ntok;     // tokens of the pass that start in this window (including a truncated last one)
+    uint32_t trunc;    // the last token has its sign bit past the end of the stream: decoding stops
+    uint32_t ends;     // the pass ends inside this window
+    uint32_t pos1;     // ... at this bit
+    uint32_t cout;
+};
+__device__ __forceinline__ LipWin lip_window(uint64_t lo, uint32_t Wb, uint32_t pos, uint32_t cin, uint32_t m_rem,
+                                             uint32_t nbits) {
+    LipWin r;
+    const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
+    uint64_t S = lip_starts(lo, pos, cin, r.cout);
+    if (vb < 64) S &= (1ull << vb) - 1ull;
+    const uint32_t cnt = (uint32_t)__popcll(S);
+    r.ends = cnt > m_rem;
+    r.pos1 = 64;
+    if (r.ends) {
+        // position of token start number m_rem (the first one that is NOT part of the pass)
+        const uint32_t lane = threadIdx.x & 63u;
+        const bool isS = (S >> lane) & 1ull;
+        const uint64_t pm = __ballot(isS && mbcnt(S) == m_rem);
+        r.pos1 = (uint32_t)__builtin_ctzll(pm);
+        S &= (1ull << r.pos1) - 1ull;
+    }
+    r.ntok = r.ends ? m_rem : cnt;
+    uint64_t sg = S & lo;
+    // a '1' whose sign bit is at or past nbits (only the very last token of the stream can be)
+    r.trunc = 0;
+    if (sg) {
+        const uint32_t top = 63u - (uint32_t)__builtin_clzll(sg);
+        if (Wb + top + 1 >= nbits) { r.trunc = 1; sg &= ~(1ull << top); S &= ~(1ull << top); }
+    }
+    r.S_in = S;
+    r.sig = sg;
+    return r;
 }
 
-__device__ __forceinline__ uint64_t readlane64(uint64_t v, uint32_t l) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)l);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)l);
-    return ((uint64_t)hi << 32) | lo;
+struct BitSrc {
+    const uint32_t *gw;   // stream words of this image
+    uint32_t nwords;      // words readable in the slot
+    uint32_t nbits;       // valid bits (8*nbytes)
+};
+
+// 32-bit stream word `wi`, zero at and past nbits
+__device__ __forceinline__ uint32_t stream_word(const BitSrc &bs, uint32_t wi) {
+    uint32_t v = 0;
+    const uint64_t b0 = (uint64_t)wi * 32;
+    if (wi < bs.nwords && b0 < bs.nbits) {
+        v = bs.gw[wi];
+        const uint32_t rem = bs.nbits - (uint32_t)b0;
+        if (rem < 32) v &= (1u << rem) - 1u;
+    }
+    return v;
 }
 
-// 64 consecutive 64-bit stream words, one per lane, so that the serial passes fetch their windows with
-// v_readlane instead of a memory access
+// 64 consecutive 64-bit stream words, one per lane: the sequencer fetches its windows with v_readlane
 struct RegChunk {
     uint64_t v;
-    uint32_t base64;  // index of lane 0's 64-bit word
+    uint32_t base64;
     uint32_t valid;
 };
-
-// sequential reader of a list in global memory through an LDS stage of DEC_LIST entries
-struct ListRd {
-    const uint32_t *src;
-    uint32_t len, lo, hi;  // entries [lo,hi) are staged
-};
-
-__device__ __forceinline__ void regchunk_load(DecShared &sh, BitSrc &bs, RegChunk &rc, uint32_t base64, uint32_t lane) {
-    // words [2*base64, 2*base64+128) must be staged
-    uint32_t wfirst = 2 * base64;
-    if (wfirst < bs.cb || wfirst + 130 > bs.cb + DEC_CH + 8) refill(sh, bs, wfirst, lane);
-    uint32_t o = wfirst - bs.cb + 2 * lane;
-    rc.v = (uint64_t)sh.w[o] | ((uint64_t)sh.w[o + 1] << 32);
-    rc.base64 = base64;
-    rc.valid = 1;
-}
-
-// (lo, hi) = 64-bit stream words widx, widx+1
-__device__ __forceinline__ void window(DecShared &sh, BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane,
-                                       uint64_t &lo, uint64_t &hi) {
-    if (!rc.valid || widx < rc.base64 || widx + 1 >= rc.base64 + 64) regchunk_load(sh, bs, rc, widx, lane);
+__device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane, uint64_t &lo,
+                                       uint64_t &hi) {
+    if (!rc.valid || widx < rc.base64 || widx + 1 >= rc.base64 + 64) {
+        const uint32_t w0 = 2 * (widx + lane);
+        rc.v = (uint64_t)stream_word(bs, w0) | ((uint64_t)stream_word(bs, w0 + 1) << 32);
+        rc.base64 = widx;
+        rc.valid = 1;
+    }
     const uint32_t k = widx - rc.base64;
     lo = readlane64(rc.v, k);
     hi = readlane64(rc.v, k + 1);
 }
 
-__device__ __forceinline__ void list_stage(DecShared &sh, ListRd &r, uint32_t from, uint32_t lane) {
-    __syncthreads();
-    r.lo = from;
-    r.hi = (r.len - from) < (uint32_t)DEC_LIST ? r.len : from + DEC_LIST;
-    uint32_t v[DEC_LIST / 64];
-#pragma unroll
-    for (int u = 0; u < DEC_LIST / 64; u++) {
-        uint32_t t = from + (uint32_t)u * 64 + lane;
-        v[u] = t < r.hi ? r.src[t] : 0u;
+// ---- sequencer side of the ring ----
+// LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
+// word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
+// half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
+__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq, const Item &it, uint32_t lane) {
+    constexpr uint32_t HALF = DEC_RING / 2;
+    if (seq >= DEC_RING && (seq % HALF) == 0) {
+        const uint32_t lim = seq - HALF;  // items [0, lim) must be done
+        for (uint32_t w = 0; w < DEC_NWK; w++) {
+            const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
+            uint32_t spins = 0;
+            while (lds_load(&sh.wdone[w]) < need) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
+            }
+        }
     }
-#pragma unroll
-    for (int u = 0; u < DEC_LIST / 64; u++) sh.lst[u * 64 + lane] = v[u];
-    __syncthreads();
-}
-// make entries [a, min(a+64,len)) available in sh.lst at offset a - r.lo
-__device__ __forceinline__ void list_need(DecShared &sh, ListRd &r, uint32_t a, uint32_t lane) {
-    uint32_t b = (r.len - a) < 64u ? r.len : a + 64;
-    if (a < r.lo || b > r.hi) list_stage(sh, r, a, lane);
+    const uint32_t w0 = it.kind | (it.pos0 << 8) | (it.pos1 << 16) | (it.cin << 24) | (it.first << 25);
+    if (lane == 0) {
+        Slot *slot = &sh.ring[seq % DEC_RING];
+        uint4 *q = reinterpret_cast<uint4 *>(slot);
+        q[0] = make_uint4(w0, it.Wb, it.e_start, it.kind ? it.b_ret : it.m_rem);
+        q[1] = make_uint4(it.b_lsp, it.b_lip, (uint32_t)it.lo, (uint32_t)(it.lo >> 32));
+        q[2] = make_uint4((uint32_t)it.hi, (uint32_t)(it.hi >> 32), (uint32_t)it.fm, (uint32_t)(it.fm >> 32));
+        asm volatile("" ::: "memory");
+        *(volatile uint32_t *)&slot->ready = seq + 1;
+    }
+    seq++;
 }
 
-__global__ __launch_bounds__(64) void k_decode(DecArgs a) {
+__device__ __forceinline__ Item slot_unpack(const Slot &s) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(&s);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    Item it;
+    it.kind = a.x & 0xFFu; it.pos0 = (a.x >> 8) & 0xFFu; it.pos1 = (a.x >> 16) & 0xFFu; it.cin = (a.x >> 24) & 1u;
+    it.first = (a.x >> 25) & 1u;
+    it.Wb = a.y; it.e_start = a.z; it.m_rem = a.w; it.b_ret = a.w; it.b_nxt = 0;
+    it.b_lsp = b.x; it.b_lip = b.y;
+    it.lo = (uint64_t)b.z | ((uint64_t)b.w << 32);
+    it.hi = (uint64_t)c.x | ((uint64_t)c.y << 32);
+    it.fm = (uint64_t)c.z | ((uint64_t)c.w << 32);
+    return it;
+}
+
+__device__ __forceinline__ void tail_push(DecShared &sh, uint32_t key, uint32_t idx, int32_t val, uint32_t n) {
+    const uint32_t tp = atomicAdd(&sh.ntail, 1u);
+    if (tp < DEC_TAIL) { sh.tail[tp].key = key; sh.tail[tp].idx = idx; sh.tail[tp].val = val; sh.tail[tp].n = n; }
+}
+
+// ---- per-lane work of one LIP window (worker) ----
+__device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const Item &it, const uint32_t *lip,
+                                         uint32_t *lipn, uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits,
+                                         uint32_t tail_start, int n, int32_t base_val, uint32_t lane) {
+    const LipWin lw = lip_window(it.lo, it.Wb, it.pos0, it.cin, it.m_rem, nbits);
+    const bool isS = (lw.S_in >> lane) & 1ull;
+    const uint32_t rank = mbcnt(lw.S_in);
+    const bool sig = (lw.sig >> lane) & 1ull;
+    const uint32_t e = isS ? lip[it.e_start + rank] : 0u;
+    if (isS && sig) {
+        const uint32_t sgn = lane < 63 ? ((uint32_t)(it.lo >> (lane + 1)) & 1u) : ((uint32_t)it.hi & 1u);
+        const uint32_t t = it.b_lsp + mbcnt(lw.sig);
+        const int32_t v = sgn ? base_val : -base_val;
+        const bool tl = it.Wb + lane + 1 >= tail_start;
+        if (t < a.caps.lsp) {
+            lsp_idx[t] = e;
+            lsp_val[t] = tl ? 0 : v;
+        }
+        if (tl) tail_push(sh, it.Wb + lane + 1, e, v, (uint32_t)n);
+    } else if (isS) {
+        lipn[it.b_lip + mbcnt(lw.S_in & ~lw.sig)] = e;
+    }
+}
+
+// ---- per-lane work of one LIS window (worker); lane = stream position inside the window ----
+__device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const Geom &g, const Item &it, uint32_t seqno,
+                                         const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
+                                         uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
+                                         int32_t base_val, uint32_t lane) {
+    const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
+    // entry starts: owned bits that are not child bits of a fired type-A entry starting in this window
+    const uint64_t own = (it.pos1 >= 64 ? ~0ull : ((1ull << it.pos1) - 1ull)) & (~0ull << it.pos0);
+    const uint64_t below = it.fm & ((1ull << lane) - 1ull);
+    bool payload = false;
+    if (below) {
+        const uint32_t f = 63u - (uint32_t)__builtin_clzll(below);
+        const uint64_t bb = f ? ((it.lo >> f) | (it.hi << (64 - f))) : it.lo;
+        uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu, ns = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            uint32_t s = pl & 1u;
+            pl >>= 1 + s;
+            ns += s;
+        }
+        payload = lane < f + 5 + ns;
+    }
+    const bool isE = ((own >> lane) & 1ull) && !payload;
+    const uint64_t ES = __ballot(isE);
+    const uint32_t mypos = it.Wb + lane;
+    const uint32_t e = isE ? cur[it.e_start + mbcnt(ES)] : 0u;
+    const uint32_t idx = e & ENT_IDX;
+    const bool isA = (e & ENT_A) != 0;
+    const bool leaf = (e & ENT_LEAF) != 0;
+    uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
+    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
+    bool fired = false;
+    if (isE) {
+        const uint32_t avail = nbits - mypos;  // >= 1: the sequencer never places an entry at or past nbits
+        const uint64_t bb = lane ? ((it.lo >> lane) | (it.hi << (64 - lane))) : it.lo;
+        const uint32_t bits = (uint32_t)bb & 0xFFFFu;
+        fired = bits & 1u;
+        if (!fired) {
+            nR = 1;
+        } else if (leaf) {
+            // a set with no offspring cannot be significant in a real stream; the reference drops the entry
+            // (no offspring to read, has_descendents_past_offspring is false too)
+            fired = false;
+        } else {
+            uint32_t k, ii, jj;
+            decomp(g, idx, k, ii, jj);
+            cb = child_base(g, k, ii, jj, cr, ccol);
+            if (!isA) {
+                nQ = 4;
+            } else {
+                bool stop = false;
+                uint32_t o = 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (!stop) {
+                        if (o >= avail) { stop = true; }
+                        else if ((bits >> o) & 1u) {
+                            if (o + 1 >= avail) { stop = true; }
+                            else {
+                                sigm |= 1u << q;
+                                signm |= ((bits >> (o + 1)) & 1u) << q;
+                                if (mypos + o + 1 >= tail_start) tailm |= 1u << q;
+                                o += 2;
+                            }
+                        } else {
+                            lipm |= 1u << q;
+                            o += 1;
+                        }
+                    }
+                }
+                nLSP = (uint32_t)__popc(sigm);
+                nLIP = (uint32_t)__popc(lipm);
+                if (!stop) nQ = (4 * ii + 3 < H && 4 * jj + 3 < W) ? 1u : 0u;  // :411-414
+            }
+        }
+    }
+    // exclusive prefix sums of the small per-lane counts, bit-sliced through ballots
+    const uint64_t mR = __ballot(nR != 0);
+    const uint64_t mQ1 = __ballot(nQ == 1), mQ4 = __ballot(nQ == 4);
+    const uint64_t mS0 = __ballot(nLSP & 1u), mS1 = __ballot(nLSP & 2u), mS2 = __ballot(nLSP & 4u);
+    const uint64_t mL0 = __ballot(nLIP & 1u), mL1 = __ballot(nLIP & 2u), mL2 = __ballot(nLIP & 4u);
+    const uint32_t tR = (uint32_t)__popcll(mR);
+    const uint32_t tQ = (uint32_t)__popcll(mQ1) + 4u * (uint32_t)__popcll(mQ4);
+    const uint32_t tLSP = (uint32_t)__popcll(mS0) + 2u * (uint32_t)__popcll(mS1) + 4u * (uint32_t)__popcll(mS2);
+    const uint32_t tLIP = (uint32_t)__popcll(mL0) + 2u * (uint32_t)__popcll(mL1) + 4u * (uint32_t)__popcll(mL2);
+    // running list lengths: from the item for the first window of a generation, else from the previous window
+    uint32_t b_lsp, b_lip, b_nxt, b_ret;
+    if (it.first) {
+        b_lsp = it.b_lsp; b_lip = it.b_lip; b_nxt = it.b_nxt; b_ret = it.b_ret;
+    } else {
+        Chain *pc = &sh.chain[(seqno - 1) % DEC_RING];
+        uint32_t spins = 0;
+        while (lds_load(&pc->seq) != seqno) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
+        }
+        b_lsp = pc->lsp; b_lip = pc->lip; b_nxt = pc->nxt; b_ret = pc->ret;
+    }
+    {
+        Chain *mc = &sh.chain[seqno % DEC_RING];
+        if (lane == 0) { mc->lsp = b_lsp + tLSP; mc->lip = b_lip + tLIP; mc->nxt = b_nxt + tQ; mc->ret = b_ret + tR; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_store(&mc->seq, seqno + 1);
+    }
+    if (b_nxt + tQ > a.caps.lis || b_ret + tR > a.caps.lis || b_lip + tLIP > a.caps.lip || b_lsp + tLSP > a.caps.lsp) {
+        if (lane == 0) sh.bad = 1;
+        return;
+    }
+    if (isE) {
+        if (nR) {
+            ret[b_ret + mbcnt(mR)] = e;
+        } else if (!fired) {
+            // fired leaf: dropped
+        } else if (!isA) {
+            const uint32_t oq = b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4);
+            nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
+            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
+            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
+            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
+        } else {
+            uint32_t ol = b_lip + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
+            uint32_t os = b_lsp + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
+            uint32_t o = 1;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t ci = cb + (q >> 1) * W + (q & 1);
+                if (sigm & (1u << q)) {
+                    const int32_t v = ((signm >> q) & 1u) ? base_val : -base_val;
+                    const bool tl = (tailm >> q) & 1u;
+                    lsp_idx[os] = ci;
+                    lsp_val[os] = tl ? 0 : v;
+                    os++;
+                    if (tl) tail_push(sh, mypos + o + 1, ci, v, (uint32_t)n);
+                    o += 2;
+                } else if (lipm & (1u << q)) {
+                    lip[ol++] = ci;
+                    o += 1;
+                }
+            }
+            if (nQ) nxt[b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = idx;  // type B
+        }
+    }
+}
+
+// worker loop of one phase: consume items until the sequencer closes the phase
+__device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, const Geom &g, uint32_t &myk, uint32_t par,
+                                             const uint32_t *lip_rd, uint32_t *lip_wr, uint32_t *lip_app,
+                                             const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lsp_idx,
+                                             int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
+                                             int32_t base_val, uint32_t wk, uint32_t lane) {
+    for (;;) {
+        bool got = false;
+        uint32_t spins = 0;
+        volatile uint32_t *rdy = &sh.ring[myk % DEC_RING].ready;
+        for (;;) {
+            if (*rdy == myk + 1) { got = true; break; }
+            const uint32_t pe = lds_load(&sh.phase_end[par]);
+            if (pe != SEQ_OPEN && pe <= myk) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
+        }
+        if (!got) break;
+        const Item it = slot_unpack(sh.ring[myk % DEC_RING]);
+        if (it.kind == 0)
+            work_lip(sh, a, it, lip_rd, lip_wr, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
+        else
+            work_lis(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
+        myk += DEC_NWK;
+    }
+}
+
+// the sequencer closes a phase: results first, then the slot of the NEXT phase is opened, then this one ends
+__device__ __forceinline__ void seq_close(DecShared &sh, uint32_t par, uint32_t seq, uint32_t P, uint32_t dn, uint32_t lsp,
+                                          uint32_t lipl, uint32_t lane) {
+    if (lane == 0) {
+        sh.r_P = P; sh.r_done = dn; sh.r_lsp = lsp; sh.r_lip = lipl;
+        sh.head = seq;
+        sh.phase_end[par ^ 1u] = SEQ_OPEN;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) lds_store(&sh.phase_end[par], seq);
+}
+
+__global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
     __shared__ DecShared sh;
     const Geom g = a.g;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t slot = blockIdx.x;
-    const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
+    const uint32_t W = (uint32_t)g.w;
 
     uint32_t *lipA = a.lip0 + (size_t)slot * a.caps.lip;
     uint32_t *lipB = a.lip1 + (size_t)slot * a.caps.lip;
@@ -255,35 +527,55 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
         const uint32_t tail_start = nbits >= 8 ? nbits - 8 : 0;
         int n = (int)a.max_n[b];
         if (n > 30) { bad = true; n = 0; }
-        refill(sh, bs, 0, lane);
-        RegChunk rc;
-        rc.v = 0; rc.base64 = 0; rc.valid = 0;
 
+        // every wave keeps its own copy of the (uniform) decoder state; the sequencer's results travel through LDS
         uint32_t *lip = lipA, *lipn = lipB;
         uint32_t *lis = q0, *qa = q1, *qb = q2;
         uint32_t lip_len = 0, lsp_len = 0, lis_len = 0;
-        uint32_t P = 0, cut = 0, ntail = 0;
+        uint32_t P = 0, cut = 0;
+        uint32_t seq = 0;                    // items produced so far (kept in step by every wave at phase ends)
+        uint32_t myk = wave ? wave - 1 : 0;  // worker: sequence number of its next item
+        uint32_t phase = 0;
+        RegChunk rc;
+        rc.v = 0; rc.base64 = 0; rc.valid = 0;
+#ifdef DEC_PROF
+        uint64_t pf[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t pt = __builtin_amdgcn_s_memtime();
+#endif
 
-        // ---- initial LIP / LIS (encoder_decoder.rs:327-348) ----
-        const uint32_t nroot = (uint32_t)(g.ll_h * g.ll_w * g.c);
-        for (uint32_t base = 0; base < nroot; base += 64) {
-            uint32_t t = base + lane;
-            bool act = t < nroot;
-            uint32_t k = 0, i = 0, j = 0;
-            if (act) {
-                uint32_t ij = t / (uint32_t)g.c;
-                k = t - ij * (uint32_t)g.c;
-                i = ij / (uint32_t)g.ll_w;
-                j = ij - i * (uint32_t)g.ll_w;
-            }
-            uint32_t idx = k * g.hw + i * W + j;
-            bool inlis = act && (((i | j) & 1u) != 0);
-            uint64_t m = __ballot(inlis);
-            if (act && t < a.caps.lip) lip[t] = idx;
-            uint32_t o = lis_len + mbcnt(m);
-            if (inlis && o < a.caps.lis) lis[o] = idx | ENT_A;
-            lis_len += (uint32_t)__popcll(m);
+        __syncthreads();  // previous image fully finished with the shared state
+        if (threadIdx.x == 0) {
+            sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.ntail = 0; sh.bad = 0;
+            for (int w = 0; w < DEC_NWK; w++) sh.wdone[w] = 0;
+            for (int r = 0; r < DEC_RING; r++) { sh.chain[r].seq = 0; sh.ring[r].ready = 0; }
         }
+
+        // ---- initial LIP / LIS (encoder_decoder.rs:327-348), wave 0 ----
+        const uint32_t nroot = (uint32_t)(g.ll_h * g.ll_w * g.c);
+        if (wave == 0) {
+            uint32_t ll = 0;
+            for (uint32_t base = 0; base < nroot; base += 64) {
+                uint32_t t = base + lane;
+                bool act = t < nroot;
+                uint32_t k = 0, i = 0, j = 0;
+                if (act) {
+                    uint32_t ij = t / (uint32_t)g.c;
+                    k = t - ij * (uint32_t)g.c;
+                    i = ij / (uint32_t)g.ll_w;
+                    j = ij - i * (uint32_t)g.ll_w;
+                }
+                uint32_t idx = k * g.hw + i * W + j;
+                bool inlis = act && (((i | j) & 1u) != 0);
+                uint64_t m = __ballot(inlis);
+                if (act && t < a.caps.lip) lip[t] = idx;
+                uint32_t o = ll + mbcnt(m);
+                if (inlis && o < a.caps.lis) lis[o] = idx | ENT_A;
+                ll += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) sh.r_lip = ll;
+        }
+        __syncthreads();
+        lis_len = sh.r_lip;
         lip_len = nroot;
         if (lip_len > a.caps.lip || lis_len > a.caps.lis) bad = true;
         __syncthreads();
@@ -293,109 +585,86 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
             const uint32_t lsp_len0 = lsp_len;
             const int32_t base_val = (n == 0) ? 1 : (int32_t)((1u << (n - 1)) + (1u << n));  // :364-370
 
-            // ---------------- LIP pass (encoder_decoder.rs:355-377) ----------------
+            // ================= LIP pass (encoder_decoder.rs:355-377) =================
             {
-                ListRd rd;
-                rd.src = lip; rd.len = lip_len; rd.lo = 0; rd.hi = 0;
-                uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0;
-                while (m_rem > 0 && !done) {
-                    if (P >= nbits) { done = true; break; }
-                    const uint32_t widx = P >> 6, pos = P & 63u, Wb = widx << 6;
-                    uint64_t Wd, Wn;
-                    window(sh, bs, rc, widx, lane, Wd, Wn);
-                    const uint32_t nxtbit = (uint32_t)Wn & 1u;
-                    const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
-                    uint32_t cout;
-                    uint64_t S = lip_starts(Wd, pos, cin, cout);
-                    if (vb < 64) S &= (1ull << vb) - 1ull;
-                    const uint32_t cnt = (uint32_t)__popcll(S);
-                    list_need(sh, rd, tok_base, lane);
-                    const bool isS = (S >> lane) & 1ull;
-                    const uint32_t rank = mbcnt(S);
-                    const bool inpass = isS && rank < m_rem;
-                    const uint32_t sig = (uint32_t)(Wd >> lane) & 1u;
-                    const bool trunc = inpass && sig && (Wb + lane + 1 >= nbits);
-                    const bool valid = inpass && !trunc;
-                    const uint32_t sgn = lane < 63 ? ((uint32_t)(Wd >> (lane + 1)) & 1u) : nxtbit;
-                    const uint32_t e = valid ? sh.lst[tok_base + rank - rd.lo] : 0u;
-                    const uint64_t sigm = __ballot(valid && sig);
-                    const uint64_t nsm = __ballot(valid && !sig);
-                    const uint32_t nsig = (uint32_t)__popcll(sigm);
-                    if (lsp_len + nsig > a.caps.lsp) { bad = true; done = true; break; }
-                    const bool istail = valid && sig && (Wb + lane + 1 >= tail_start);
-                    const uint64_t tm = __ballot(istail);
-                    if (valid && sig) {
-                        uint32_t t = lsp_len + mbcnt(sigm);
-                        int32_t v = sgn ? base_val : -base_val;
-                        lsp_idx[t] = e;
-                        lsp_val[t] = istail ? 0 : v;
-                        if (istail) {
-                            uint32_t tp = ntail + mbcnt(tm);
-                            if (tp < DEC_TAIL) { sh.tail[tp].idx = e; sh.tail[tp].val = v; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 0; }
+                const uint32_t par = phase & 1u;
+                PF_ADD(7);
+                if (wave == 0) {
+                    uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0, lsp_l = lsp_len, dn = 0;
+                    while (m_rem > 0) {
+                        if (P >= nbits) { dn = 1; break; }
+                        const uint32_t widx = P >> 6, pos = P & 63u, Wb = widx << 6;
+                        uint64_t lo, hi;
+                        window(bs, rc, widx, lane, lo, hi);
+                        const LipWin lw = lip_window(lo, Wb, pos, cin, m_rem, nbits);
+                        const uint32_t nsig = (uint32_t)__popcll(lw.sig);
+                        const uint32_t nnon = (uint32_t)__popcll(lw.S_in & ~lw.sig);
+                        if (lsp_l + nsig > a.caps.lsp) { if (lane == 0) sh.bad = 1; dn = 1; break; }
+                        Item it;
+                        it.kind = 0; it.Wb = Wb; it.pos0 = pos; it.pos1 = lw.pos1; it.e_start = tok_base; it.cin = cin;
+                        it.m_rem = m_rem; it.first = 1; it.b_lsp = lsp_l; it.b_lip = lipn_len; it.b_nxt = 0; it.b_ret = 0;
+                        it.lo = lo; it.hi = hi; it.fm = 0;
+                        seq_publish(sh, seq, it, lane);
+                        lsp_l += nsig;
+                        lipn_len += nnon;
+                        if (lw.trunc) { dn = 1; cin = 0; break; }
+                        if (lw.ends) {
+                            P = Wb + lw.pos1;
+                            m_rem = 0;
+                            cin = 0;
+                        } else {
+                            m_rem -= lw.ntok;
+                            tok_base += lw.ntok;
+                            P = Wb + 64;
+                            cin = lw.cout;
                         }
-                    } else if (valid) {
-                        lipn[lipn_len + mbcnt(nsm)] = e;
                     }
-                    ntail += (uint32_t)__popcll(tm);
-                    lsp_len += nsig;
-                    lipn_len += (uint32_t)__popcll(nsm);
-                    if (__ballot(trunc)) { done = true; break; }
-                    if (cnt > m_rem) {
-                        // the pass ends inside this window, at the start of token number m_rem
-                        uint64_t pm = __ballot(isS && rank == m_rem);
-                        P = Wb + (uint32_t)__builtin_ctzll(pm);
-                        m_rem = 0;
-                        cin = 0;
-                    } else {
-                        m_rem -= cnt;
-                        tok_base += cnt;
-                        P = Wb + 64;
-                        cin = cout;
-                    }
+                    if (cin) P += 1;
+                    seq_close(sh, par, seq, P, dn, lsp_l, lipn_len, lane);
+                } else {
+                    worker_phase(sh, a, g, myk, par, lip, lipn, nullptr, nullptr, nullptr, nullptr, lsp_idx, lsp_val, nbits,
+                                 tail_start, n, base_val, wave - 1, lane);
                 }
-                if (cin) P += 1;
+                PF_ADD(0);
+                __syncthreads();
+                phase++;
+                P = sh.r_P; lsp_len = sh.r_lsp; lip_len = sh.r_lip;
+                if (sh.r_done || sh.bad) done = true;
+                PF_CNT(5, sh.head - seq);
+                seq = sh.head;
                 { uint32_t *t = lip; lip = lipn; lipn = t; }
-                lip_len = lipn_len;
+                __syncthreads();
+                PF_ADD(1);
             }
             if (done) break;
 
-            // ---------------- LIS pass (encoder_decoder.rs:379-436) ----------------
+            // ================= LIS pass (encoder_decoder.rs:379-436) =================
             uint32_t *cur = lis, *nxt = qa, *ret = qb;
             uint32_t cur_len = lis_len, ret_len = 0;
             while (cur_len > 0 && !done) {
-                uint32_t nxt_len = 0;
-                ListRd rd;
-                rd.src = cur; rd.len = cur_len; rd.lo = 0; rd.hi = 0;
-                for (uint32_t e0 = 0; e0 < cur_len && !done; e0 += 64) {
-                    const uint32_t nE = (cur_len - e0) < 64u ? (cur_len - e0) : 64u;
-                    const bool act = lane < nE;
-                    list_need(sh, rd, e0, lane);
-                    const uint32_t e = act ? sh.lst[e0 + lane - rd.lo] : 0u;
-                    const uint32_t idx = e & ENT_IDX;
-                    const bool isA = (e & ENT_A) != 0;
-                    // only a type-A entry WITH offspring is followed by child bits when it fires
-                    const bool leaf = (e & ENT_LEAF) != 0;
-                    const uint64_t TA = __ballot(act && isA && !leaf);
-                    // the window's bits span at most 64*9 positions; stage them now so the walk and the
-                    // per-entry gathers below never trigger a refill in between
-                    // (a register-chunk reload wants 130 words past its base: cover that too)
-                    ensure(sh, bs, P, 64 * 9 + 130 * 32 + 256, lane);
-                    // ---- position walk (uniform control flow): hop from fired type-A entry to fired type-A entry;
-                    //      everything in between takes exactly one bit.  Each hop records a segment: entries
-                    //      [i, ...) sit at stream position delta + entry index ----
-                    uint64_t segmask = 0;
-                    uint32_t nseg = 0, i = 0;
-                    while (i < nE && P < nbits) {
-                        const uint32_t widx = P >> 6, Wb = widx << 6;
-                        uint32_t pos = P & 63u;
+                const uint32_t par = phase & 1u;
+                const uint32_t seq0 = seq;  // every wave enters the phase with seq == head
+                if (wave == 0) {
+                    uint32_t i = 0, dn = 0, first = 1;
+                    // type mask of queue entries [Ebase, Ebase+64): bit = type A with offspring
+                    uint32_t Ebase = 0;
+                    uint32_t ent = lane < cur_len ? cur[lane] : 0u;
+                    uint32_t ent_nx = (64 + lane) < cur_len ? cur[64 + lane] : 0u;
+                    uint64_t TA = __ballot((ent & ENT_A) && !(ent & ENT_LEAF));
+                    while (i < cur_len) {
+                        if (P >= nbits) { dn = 1; break; }
+                        const uint32_t widx = P >> 6, Wb = widx << 6, pos0 = P & 63u;
+                        uint32_t pos = pos0;
                         uint64_t lo, hi;
-                        window(sh, bs, rc, widx, lane, lo, hi);
+#ifdef DEC_PROF
+                        const uint64_t tw = __builtin_amdgcn_s_memtime();
+#endif
+                        window(bs, rc, widx, lane, lo, hi);
                         // length of a fired type-A entry starting at window position `lane`
                         uint32_t LAv;
                         {
-                            uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
-                            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu;
-                            uint32_t ns = 0;
+                            const uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
+                            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu, ns = 0;
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 uint32_t s = pl & 1u;
@@ -405,136 +674,126 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
                             LAv = 5 + ns;
                         }
                         const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
-                        while (i < nE && pos < vb) {
-                            const uint64_t cand = lo & ((TA >> i) << pos);  // TA has no bits at or past nE
-                            segmask |= 1ull << i;
-                            if (lane == 0) sh.seg[nseg] = Wb + pos - i;
-                            nseg++;
-                            if (cand == 0) {
-                                const uint32_t z = (vb - pos) < (nE - i) ? (vb - pos) : (nE - i);
-                                i += z;
-                                pos += z;
-                            } else {
+                        const uint32_t i0 = i;
+                        uint64_t fm = 0;
+#ifdef DEC_PROF
+                        const uint64_t th = __builtin_amdgcn_s_memtime();
+                        pf[12] += th - tw;
+#endif
+                        for (;;) {  // one pass per chunk of 64 queue entries met inside this window
+                            if (i >= Ebase + 64) {
+                                Ebase += 64;
+                                ent = ent_nx;
+                                ent_nx = (Ebase + 64 + lane) < cur_len ? cur[Ebase + 64 + lane] : 0u;
+                                TA = __ballot((ent & ENT_A) && !(ent & ENT_LEAF));
+                            }
+                            uint32_t rel = i - Ebase;
+                            const uint32_t nEw = (cur_len - Ebase) < 64u ? (cur_len - Ebase) : 64u;
+                            // TA has no bits at or past nEw and `lo` none at or past vb: a candidate is always in range
+#ifdef DEC_HOP_C
+                            do {
+                                const uint64_t cand = lo & ((TA >> rel) << pos);
+                                if (cand == 0) {
+                                    const uint32_t z = (vb - pos) < (nEw - rel) ? (vb - pos) : (nEw - rel);
+                                    rel += z;
+                                    pos += z;
+                                    break;
+                                }
                                 const uint32_t f = (uint32_t)__builtin_ctzll(cand);
+                                fm |= 1ull << f;
+                                PF_CNT(10, 1);
                                 const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)LAv, (int)f);
-                                i += f - pos + 1;
+                                rel += f - pos + 1;
                                 pos = f + len;
+                            } while (pos < vb && rel < nEw);
+#else
+                            // The same loop, hand-scheduled: this serial chain bounds the whole decoder and hipcc's
+                            // version of it is twice as long (uniform conditions routed through VCC/EXEC).  All scalar:
+                            // s_and sets SCC (= candidate exists); five SALU instructions separate s_ff1 from the
+                            // v_readlane that uses its result as lane select (4 wait states needed).
+                            {
+                                uint64_t t64;
+                                uint32_t f, dd, len;
+                                // tell the compiler these wave-uniform values live in SGPRs
+                                rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
+                                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+                                const uint32_t vb_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb);
+                                const uint32_t nEw_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)nEw);
+                                asm volatile(
+                                    "s_hop_loop%=:\n\t"
+                                    "s_lshr_b64 %[t], %[TA], %[rel]\n\t"
+                                    "s_lshl_b64 %[t], %[t], %[pos]\n\t"
+                                    "s_and_b64 %[t], %[t], %[lo]\n\t"
+                                    "s_cbranch_scc0 s_hop_none%=\n\t"
+                                    "s_ff1_i32_b64 %[f], %[t]\n\t"
+                                    "s_bitset1_b64 %[fm], %[f]\n\t"
+                                    "s_sub_i32 %[d], %[f], %[pos]\n\t"
+                                    "s_add_i32 %[rel], %[rel], %[d]\n\t"
+                                    "s_add_i32 %[rel], %[rel], 1\n\t"
+                                    "s_nop 0\n\t"
+                                    "v_readlane_b32 %[len], %[LAv], %[f]\n\t"
+                                    "s_add_i32 %[pos], %[f], %[len]\n\t"
+                                    "s_cmp_lt_u32 %[pos], %[vb]\n\t"
+                                    "s_cbranch_scc0 s_hop_done%=\n\t"
+                                    "s_cmp_lt_u32 %[rel], %[nEw]\n\t"
+                                    "s_cbranch_scc1 s_hop_loop%=\n\t"
+                                    "s_branch s_hop_done%=\n"
+                                    "s_hop_none%=:\n\t"
+                                    "s_sub_i32 %[d], %[vb], %[pos]\n\t"
+                                    "s_sub_i32 %[f], %[nEw], %[rel]\n\t"
+                                    "s_min_u32 %[d], %[d], %[f]\n\t"
+                                    "s_add_i32 %[rel], %[rel], %[d]\n\t"
+                                    "s_add_i32 %[pos], %[pos], %[d]\n"
+                                    "s_hop_done%=:\n\t"
+                                    : [rel] "+s"(rel), [pos] "+s"(pos), [fm] "+s"(fm), [t] "=&s"(t64), [f] "=&s"(f), [d] "=&s"(dd),
+                                      [len] "=&s"(len)
+                                    : [TA] "s"(TA), [lo] "s"(lo), [vb] "s"(vb_s), [nEw] "s"(nEw_s), [LAv] "v"(LAv)
+                                    : "scc");
                             }
+#endif
+                            i = Ebase + rel;
+                            if (pos >= vb || i >= cur_len) break;
                         }
+#ifdef DEC_PROF
+                        pf[13] += __builtin_amdgcn_s_memtime() - th;
+#endif
+                        Item it;
+                        it.kind = 1; it.Wb = Wb; it.pos0 = pos0; it.pos1 = pos < 64u ? pos : 64u; it.e_start = i0; it.cin = 0;
+                        it.m_rem = 0; it.first = first; it.b_lsp = lsp_len; it.b_lip = lip_len; it.b_nxt = 0; it.b_ret = ret_len;
+                        it.lo = lo; it.hi = hi; it.fm = fm;
+#ifdef DEC_PROF
+                        const uint64_t tq = __builtin_amdgcn_s_memtime();
+#endif
+                        seq_publish(sh, seq, it, lane);
+#ifdef DEC_PROF
+                        pf[11] += __builtin_amdgcn_s_memtime() - tq;
+#endif
+                        first = 0;
                         P = Wb + pos;
+                        if (P > nbits) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
                     }
-                    uint32_t mypos = POS_INVALID;
-                    {
-                        const uint32_t sidx = (uint32_t)__popcll(segmask & ((2ull << lane) - 1ull));
-                        const uint32_t dl = sh.seg[sidx ? sidx - 1 : 0];
-                        if (lane < i) mypos = dl + lane;
-                    }
-                    // ---- per-entry outputs ----
-                    const bool have = act && mypos != POS_INVALID && mypos < nbits;
-                    bool stop = act && !have;
-                    uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
-                    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
-                    bool fired = false;
-                    if (have) {
-                        const uint32_t avail = nbits - mypos;
-                        const uint32_t bits = (uint32_t)peek64(sh, bs, mypos) & 0xFFFFu;
-                        fired = bits & 1u;
-                        if (!fired) {
-                            nR = 1;
-                        } else if (leaf) {
-                            // a set with no offspring cannot be significant in a real stream; the reference drops
-                            // the entry (no offspring to read, has_descendents_past_offspring is false too)
-                            fired = false;
-                        } else {
-                            uint32_t k, ii, jj;
-                            decomp(g, idx, k, ii, jj);
-                            cb = child_base(g, k, ii, jj, cr, ccol);
-                            if (!isA) {
-                                nQ = 4;
-                            } else {
-                                uint32_t o = 1;
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    if (!stop) {
-                                        if (o >= avail) { stop = true; }
-                                        else if ((bits >> o) & 1u) {
-                                            if (o + 1 >= avail) { stop = true; }
-                                            else {
-                                                sigm |= 1u << q;
-                                                signm |= ((bits >> (o + 1)) & 1u) << q;
-                                                if (mypos + o + 1 >= tail_start) tailm |= 1u << q;
-                                                o += 2;
-                                            }
-                                        } else {
-                                            lipm |= 1u << q;
-                                            o += 1;
-                                        }
-                                    }
-                                }
-                                nLSP = (uint32_t)__popc(sigm);
-                                nLIP = (uint32_t)__popc(lipm);
-                                if (!stop) nQ = (4 * ii + 3 < H && 4 * jj + 3 < W) ? 1u : 0u;  // :411-414
-                            }
-                        }
-                    }
-                    // exclusive prefix sums of the small per-lane counts, bit-sliced through ballots
-                    const uint64_t mR = __ballot(nR != 0);
-                    const uint64_t mQ1 = __ballot(nQ == 1), mQ4 = __ballot(nQ == 4);
-                    const uint64_t mS0 = __ballot(nLSP & 1u), mS1 = __ballot(nLSP & 2u), mS2 = __ballot(nLSP & 4u);
-                    const uint64_t mL0 = __ballot(nLIP & 1u), mL1 = __ballot(nLIP & 2u), mL2 = __ballot(nLIP & 4u);
-                    const uint32_t tR = (uint32_t)__popcll(mR);
-                    const uint32_t tQ = (uint32_t)__popcll(mQ1) + 4u * (uint32_t)__popcll(mQ4);
-                    const uint32_t tLSP = (uint32_t)__popcll(mS0) + 2u * (uint32_t)__popcll(mS1) + 4u * (uint32_t)__popcll(mS2);
-                    const uint32_t tLIP = (uint32_t)__popcll(mL0) + 2u * (uint32_t)__popcll(mL1) + 4u * (uint32_t)__popcll(mL2);
-                    if (nxt_len + tQ > a.caps.lis || ret_len + tR > a.caps.lis || lip_len + tLIP > a.caps.lip ||
-                        lsp_len + tLSP > a.caps.lsp) { bad = true; done = true; break; }
-                    const uint64_t mT = __ballot(tailm != 0);
-                    uint32_t exT = 0, tT = 0;
-                    if (mT) {  // rare: an entry consumed one of the last 8 bits
-                        uint64_t tot;
-                        uint64_t ex = wave_exscan((uint64_t)__popc(tailm), tot, lane);
-                        exT = (uint32_t)ex;
-                        tT = (uint32_t)tot;
-                    }
-                    if (have) {
-                        if (nR) {
-                            ret[ret_len + mbcnt(mR)] = e;
-                        } else if (!fired) {
-                            // fired leaf: dropped
-                        } else if (!isA) {
-                            uint32_t oq = nxt_len + mbcnt(mQ1) + 4u * mbcnt(mQ4);
-                            nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
-                            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
-                            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
-                            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
-                        } else {
-                            uint32_t ol = lip_len + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
-                            uint32_t os = lsp_len + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
-                            uint32_t ot = ntail + exT;
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                uint32_t ci = cb + (q >> 1) * W + (q & 1);
-                                if (sigm & (1u << q)) {
-                                    int32_t v = ((signm >> q) & 1u) ? base_val : -base_val;
-                                    bool tl = (tailm >> q) & 1u;
-                                    lsp_idx[os] = ci;
-                                    lsp_val[os] = tl ? 0 : v;
-                                    os++;
-                                    if (tl) {
-                                        if (ot < DEC_TAIL) { sh.tail[ot].idx = ci; sh.tail[ot].val = v; sh.tail[ot].n = (uint32_t)n; sh.tail[ot].kind = 0; }
-                                        ot++;
-                                    }
-                                } else if (lipm & (1u << q)) {
-                                    lip[ol++] = ci;
-                                }
-                            }
-                            if (nQ) nxt[nxt_len + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = idx;  // type B
-                        }
-                    }
-                    nxt_len += tQ; ret_len += tR; lip_len += tLIP; lsp_len += tLSP; ntail += tT;
-                    if (__ballot(stop)) done = true;
+                    if (i < cur_len) dn = 1;  // stream exhausted before the queue
+                    seq_close(sh, par, seq, P, dn, 0, 0, lane);
+                } else {
+                    worker_phase(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits, tail_start,
+                                 n, base_val, wave - 1, lane);
                 }
-                __syncthreads();  // entries of the next generation are read back through the LDS stage
+                PF_ADD(2);
+                __syncthreads();
+                phase++;
+                PF_CNT(8, 1);
+                const uint32_t seq_end = sh.head;
+                PF_CNT(6, seq_end - seq0);
+                uint32_t nxt_len = 0;
+                if (seq_end > seq0) {  // running lengths after the generation's last window
+                    const Chain *lc = &sh.chain[(seq_end - 1) % DEC_RING];
+                    lsp_len = lc->lsp; lip_len = lc->lip; nxt_len = lc->nxt; ret_len = lc->ret;
+                }
+                seq = seq_end;
+                P = sh.r_P;
+                if (sh.r_done || sh.bad) done = true;
+                __syncthreads();
+                PF_ADD(3);
                 { uint32_t *t = cur; cur = nxt; nxt = t; }
                 cur_len = nxt_len;
             }
@@ -542,65 +801,71 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
             lis = ret; lis_len = ret_len;
             qa = cur; qb = nxt;
 
-            // ---------------- refinement (encoder_decoder.rs:438-444) ----------------
+            // ================= refinement (encoder_decoder.rs:438-444): all wavefronts =================
             {
                 const uint32_t left = nbits > P ? nbits - P : 0u;
                 const uint32_t count = lsp_len0 < left ? lsp_len0 : left;
-                for (uint32_t t0 = 0; t0 < count; t0 += 256) {
-                    ensure(sh, bs, P + t0, 256 + 64, lane);
+                for (uint32_t t0 = wave * 256u; t0 < count; t0 += DEC_NW * 256u) {
                     int32_t v[4];
                     uint32_t bit[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        uint32_t t = t0 + (uint32_t)u * 64 + lane;
+                        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
                         v[u] = t < count ? lsp_val[t] : 0;
-                        uint32_t pos = P + t;
-                        bit[u] = t < count ? ((sh.w[(pos >> 5) - bs.cb] >> (pos & 31)) & 1u) : 0u;
+                        const uint32_t pos = P + t;
+                        bit[u] = t < count ? ((bs.gw[pos >> 5] >> (pos & 31)) & 1u) : 0u;
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        uint32_t t = t0 + (uint32_t)u * 64 + lane;
+                        const uint32_t t = t0 + (uint32_t)u * 64 + lane;
                         const bool in = t < count;
                         const bool tl = in && (P + t >= tail_start);
                         if (in && !tl) lsp_val[t] = set_bit_i32(v[u], (uint32_t)n, bit[u]);
-                        const uint64_t tm = __ballot(tl);
-                        if (tm) {
-                            if (tl) {
-                                uint32_t tp = ntail + mbcnt(tm);
-                                if (tp < DEC_TAIL) { sh.tail[tp].idx = lsp_idx[t]; sh.tail[tp].val = (int32_t)bit[u]; sh.tail[tp].n = (uint32_t)n; sh.tail[tp].kind = 1; }
-                            }
-                            ntail += (uint32_t)__popcll(tm);
-                        }
+                        if (tl) tail_push(sh, P + t, lsp_idx[t], (int32_t)bit[u], (uint32_t)n | 0x80000000u);
                     }
                 }
                 P += count;
                 if (count < lsp_len0) { cut = count; done = true; }
+                __syncthreads();
+                PF_ADD(4);
             }
             if (n == 0) break;
         }
 
         // ---------------- scatter decoded values ----------------
         __syncthreads();
-        for (uint32_t t = cut + lane; t < lsp_len; t += 64) {
+        for (uint32_t t = cut + threadIdx.x; t < lsp_len; t += DEC_NW * 64) {
             int32_t v = lsp_val[t];
             if (v) out[lsp_idx[t]] = v;
         }
-        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        for (uint32_t t = lane; t < cut; t += 64) {
+        for (uint32_t t = threadIdx.x; t < cut; t += DEC_NW * 64) {
             int32_t v = lsp_val[t];
             if (v) out[lsp_idx[t]] = v;
         }
-        __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (lane == 0) {
-            uint32_t nt = ntail < DEC_TAIL ? ntail : DEC_TAIL;
+        if (threadIdx.x == 0) {
+            const uint32_t nt = sh.ntail < DEC_TAIL ? sh.ntail : DEC_TAIL;
+            // replay in stream order (keys are distinct bit positions)
             for (uint32_t q = 0; q < nt; q++) {
-                TailOp op = sh.tail[q];
-                if (op.kind == 0) out[op.idx] = op.val;
-                else out[op.idx] = set_bit_i32(out[op.idx], op.n, (uint32_t)op.val);
+                uint32_t best = 0xFFFFFFFFu, bi = 0;
+                for (uint32_t r = 0; r < nt; r++)
+                    if (sh.tail[r].key < best) { best = sh.tail[r].key; bi = r; }
+                TailOp op = sh.tail[bi];
+                sh.tail[bi].key = 0xFFFFFFFFu;
+                if (op.n & 0x80000000u) out[op.idx] = set_bit_i32(out[op.idx], op.n & 0xFFu, (uint32_t)op.val);
+                else out[op.idx] = op.val;
             }
-            if (bad || ntail > DEC_TAIL) atomicOr(a.err, 1u);
+            uint32_t ecode = 0;
+            if (bad) ecode |= 1u | 0x100u;
+            if (sh.bad == 1) ecode |= 1u | 0x200u;            // list capacity
+            if (sh.bad == 2) ecode |= 1u | 0x400u;            // spin limit
+            if (sh.ntail > DEC_TAIL) ecode |= 1u | 0x800u;
+            if (ecode) atomicOr(a.err, ecode);
+#ifdef DEC_PROF
+            PF_ADD(9);
+            if (b == 0) for (int q = 0; q < 14; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 ? pf[q] : (pf[q] >> 10));
+#endif
         }
         __syncthreads();
     }
@@ -609,6 +874,6 @@ __global__ __launch_bounds__(64) void k_decode(DecArgs a) {
 extern "C" int spiht_launch_decode(const DecArgs *a, hipStream_t st) {
     int grid = a->nslots < a->B ? a->nslots : a->B;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(64), 0, st, *a);
+    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
     return (int)hipGetLastError();
 }

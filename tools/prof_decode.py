@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Diagnostic: where the decoder's sequencer wavefront spends its time (needs the -DDEC_PROF build:
+SPIHT_HIP_LIB=spiht_amd/libspiht_hip_prof.so python tools/prof_decode.py [batch])."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spiht_amd import _lib
+from spiht_amd.batch import BatchCodec, DeviceArray
+from spiht_amd.spiht_wrapper import SpihtSettings
+from bench import synth_image, H, W, C_IMG, LEVEL, BPP
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+ctx = _lib.default_context(0)
+L = _lib.lib()
+codec = BatchCodec(C_IMG, H, W, SpihtSettings(), LEVEL, int(H * W * BPP), ctx=ctx)
+g = codec.geom
+img = synth_image(1000, C_IMG, H, W)
+d_img = DeviceArray(ctx, (B, C_IMG, H, W), np.float64)
+for b in range(B):
+    d_img.upload(img, offset_bytes=b * C_IMG * H * W * 8)
+d_out = DeviceArray(ctx, (B, codec.slot_stride), np.uint8)
+d_nbits = DeviceArray(ctx, (B,), np.uint64)
+d_nbytes = DeviceArray(ctx, (B,), np.uint64)
+d_maxn = DeviceArray(ctx, (B,), np.uint8)
+d_rec = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
+codec.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
+codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
+vp = C.c_void_p
+for _ in range(2):
+    _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B,
+                                        C_IMG, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], vp(d_rec.ptr)))
+ctx.synchronize()
+words = (C.c_uint32 * 64)()
+L.spiht_debug_words.argtypes = [vp, vp]
+_lib.check(L.spiht_debug_words(ctx.handle, words))
+w = list(words)[16:30]
+names = ["lip_seq", "lip_wait", "lis_seq", "lis_wait", "refine", "items_lip", "items_lis", "other", "generations", "scatter", "hops", "lis_publish", "lis_window", "lis_hops"]
+tot = sum(w[k] for k in (0, 1, 2, 3, 4, 7, 9))
+for k, nm in enumerate(names):
+    if k in (5, 6, 8, 10):
+        print("%-12s %d" % (nm, w[k]))
+    else:
+        print("%-12s %8.3f Mcycles (%.1f%%)" % (nm, w[k] * 1024 / 1e6, 100.0 * w[k] / max(tot, 1)))
+print("total %.3f Mticks (s_memtime ticks; 100 MHz => %.2f ms)" % (tot * 1024 / 1e6, tot * 1024 / 1e5 / 1e3))
