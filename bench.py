@@ -85,25 +85,34 @@ def main():
     for b in range(B):
         d_img.upload(base[b % nd], offset_bytes=b * per)
     d_rec_img = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
-    d_nbits = DeviceArray(ctx, (B,), np.uint64)
     d_nbytes = DeviceArray(ctx, (B,), np.uint64)
-    d_maxn = DeviceArray(ctx, (B,), np.uint8)
     if dist is not None:
+        # buffers the collective touches are torch tensors (RCCL needs them); the codec only sees their pointers
         out_t = torch.zeros((B, slot), dtype=torch.uint8, device="cuda")
+        nbits_t = torch.zeros((B,), dtype=torch.int64, device="cuda")
+        maxn_t = torch.zeros((B,), dtype=torch.uint8, device="cuda")
         gathered = torch.zeros((world * B, slot), dtype=torch.uint8, device="cuda")
-        out_ptr = out_t.data_ptr()
+        g_nbits = torch.zeros((world * B,), dtype=torch.int64, device="cuda")
+        g_maxn = torch.zeros((world * B,), dtype=torch.uint8, device="cuda")
+        out_ptr, nbits_ptr, maxn_ptr = out_t.data_ptr(), nbits_t.data_ptr(), maxn_t.data_ptr()
     else:
         d_out = DeviceArray(ctx, (B, slot), np.uint8)
-        out_ptr = d_out.ptr
+        d_nbits = DeviceArray(ctx, (B,), np.uint64)
+        d_maxn = DeviceArray(ctx, (B,), np.uint8)
+        out_ptr, nbits_ptr, maxn_ptr = d_out.ptr, d_nbits.ptr, d_maxn.ptr
 
     def step():
-        codec.encode_device(d_img.ptr, B, out_ptr, d_nbits.ptr, d_maxn.ptr)
+        codec.encode_device(d_img.ptr, B, out_ptr, nbits_ptr, maxn_ptr)
         if dist is not None:
+            # the one exchange of the path: fixed-size stream slots + bit counts + start planes,
+            # rank-major (spiht_amd/dist.py: rank r owns rows [r*B, (r+1)*B))
             ctx.synchronize()
-            dist.all_gather_into_tensor(gathered, out_t)  # the one collective of the path
+            dist.all_gather_into_tensor(gathered, out_t)
+            dist.all_gather_into_tensor(g_nbits, nbits_t)
+            dist.all_gather_into_tensor(g_maxn, maxn_t)
             torch.cuda.synchronize()
-        codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
-        codec.decode_device(out_ptr, d_nbytes.ptr, d_maxn.ptr, B, d_rec_img.ptr)
+        codec.nbits_to_nbytes(nbits_ptr, B, d_nbytes.ptr)
+        codec.decode_device(out_ptr, d_nbytes.ptr, maxn_ptr, B, d_rec_img.ptr)
 
     def sync_all():
         ctx.synchronize()
@@ -131,8 +140,15 @@ def main():
         dt = float(tt.item())
 
     # ---- correctness of what was timed (outside the timed region) ----
-    nbits = d_nbits.download()
-    maxn = d_maxn.download()
+    nbits = np.empty(B, np.uint64)
+    maxn = np.empty(B, np.uint8)
+    ctx.download(nbits, nbits_ptr)
+    ctx.download(maxn, maxn_ptr)
+    gather_ok = None
+    if dist is not None:
+        # the gathered rows of this rank must be its own slots
+        gather_ok = bool(torch.equal(gathered[rank * B:(rank + 1) * B], out_t) and
+                         torch.equal(g_nbits[rank * B:(rank + 1) * B], nbits_t))
     rec0 = np.empty((C_IMG, g["rec_h"], g["rec_w"]), np.float64)
     ctx.download(rec0, d_rec_img.ptr)
     mae = float(np.abs(rec0[:, :H, :W] - base[0]).mean())
@@ -171,7 +187,7 @@ def main():
                          "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4)},
             "stages_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in stages.items() if v[1]},
             "check": {"nbits_all_equal_budget": bool((nbits == max_bits).all()), "max_n": int(maxn[0]),
-                      "mean_abs_err_image0": round(mae, 5)},
+                      "mean_abs_err_image0": round(mae, 5), "gather_rows_match": gather_ok},
         }
 
         # ---- CPU baseline: the oracle (port of the reference algorithm) on a bounded sample, one core ----

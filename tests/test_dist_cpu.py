@@ -1,0 +1,116 @@
+"""CPU tests of the multi-GPU path: world_size-2 gloo processes shard a batch image-per-rank, code their shard
+(with the CPU oracle standing in for the GPU -- this tests the sharding/gather logic, not the kernels), all-gather
+the fixed-size stream slots and check that every rank reassembles exactly the streams a single process makes."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import synth_image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_properties():
+    from spiht_amd.dist import owner_of, padded_count, partition
+    for total in [0, 1, 5, 8, 13, 256, 2048]:
+        for world in [1, 2, 3, 8]:
+            seen = []
+            for r in range(world):
+                a, b = partition(total, world, r)
+                assert 0 <= a <= b <= total
+                assert b - a <= padded_count(total, world)
+                seen.extend(range(a, b))
+                for i in range(a, b):
+                    assert owner_of(i, total, world) == r
+            assert seen == list(range(total))
+    assert partition(2048, 8, 3) == (768, 1024)  # BASELINE config 4: 256 images per GPU
+    with pytest.raises(ValueError):
+        partition(4, 2, 2)
+
+
+def test_pack_unpack_roundtrip():
+    from spiht_amd.dist import pack_slots, padded_count, partition, unpack_gathered
+    rng = np.random.default_rng(0)
+    total, world, slot = 7, 3, 64
+    streams = [(rng.integers(0, 256, int(rng.integers(0, 60)), dtype=np.uint8).tobytes(), int(rng.integers(0, 14)))
+               for _ in range(total)]
+    per = padded_count(total, world)
+    parts = []
+    for r in range(world):
+        a, b = partition(total, world, r)
+        parts.append(pack_slots(streams[a:b], slot, per))
+    slots = np.concatenate([p[0] for p in parts])
+    nbytes = np.concatenate([p[1] for p in parts])
+    maxn = np.concatenate([p[2] for p in parts])
+    assert unpack_gathered(slots, nbytes, maxn, total, world) == streams
+    with pytest.raises(ValueError):
+        pack_slots([(b"x" * 70, 1)], slot)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import torch
+        import torch.distributed as dist
+        from oracle import oracle as O
+        from spiht_amd.dist import pack_slots, padded_count, partition, unpack_gathered
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        c, H, W, level, max_bits = 3, 40, 56, 2, 2500
+        slot = ((max_bits + 7) // 8 + 3) & ~3
+        a, b = partition(total, world, rank)
+        mine = []
+        for i in range(a, b):  # image i of the batch has seed 1000 + i
+            data, mn, _ = O.encode_image(synth_image(1000 + i, c, H, W), "bior2.2", "reflect", level, 50.0, None, max_bits)
+            mine.append((data, mn))
+        per = padded_count(total, world)
+        slots, nbytes, maxn = pack_slots(mine, slot, per)
+        g_slots = torch.zeros((world * per, slot), dtype=torch.uint8)
+        g_nb = torch.zeros(world * per, dtype=torch.int64)
+        g_mn = torch.zeros(world * per, dtype=torch.uint8)
+        dist.all_gather_into_tensor(g_slots, torch.from_numpy(slots))
+        dist.all_gather_into_tensor(g_nb, torch.from_numpy(nbytes.astype(np.int64)))
+        dist.all_gather_into_tensor(g_mn, torch.from_numpy(maxn))
+        got = unpack_gathered(g_slots.numpy(), g_nb.numpy().astype(np.uint64), g_mn.numpy(), total, world)
+        # every rank decodes the image it does NOT own from the gathered slots and checks it against a local encode
+        other = (b % total) if total else 0
+        ref, mn, _ = O.encode_image(synth_image(1000 + other, c, H, W), "bior2.2", "reflect", level, 50.0, None, max_bits)
+        ok = got[other] == (ref, mn) and len(got) == total
+        dec = O.decode_image(got[other][0], got[other][1], c, H, W, "bior2.2", level, 50.0, None)
+        ok = ok and dec.shape == (c, H, W)
+        dist.barrier()
+        dist.destroy_process_group()
+        import hashlib
+        q.put((rank, ok, [hashlib.sha1(s[0] + bytes([s[1]])).hexdigest() for s in got]))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, False, repr(e)))
+
+
+@pytest.mark.parametrize("total", [4, 5])
+def test_two_rank_gloo_gather(total, oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort()
+    assert all(r[1] is True for r in res), res
+    assert res[0][2] == res[1][2]  # both ranks hold the same gathered streams

@@ -1,0 +1,180 @@
+"""GPU tests of the image-level API (spiht_wrapper counterpart, batched codec) against the CPU oracle, including
+BASELINE.json's configurations at full size."""
+import numpy as np
+import pytest
+
+from conftest import synth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_roundtrip(O, img, settings, level, max_bits):
+    data, max_n, g = O.encode_image(img, settings.wavelet, settings.mode, level, settings.quantization_scale,
+                                    settings.per_channel_quant_scales, max_bits)
+    c, H, W = img.shape
+    dec = O.decode_image(data, max_n, c, H, W, settings.wavelet, level, settings.quantization_scale,
+                         settings.per_channel_quant_scales)
+    return data, max_n, dec
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(c=1, H=32, W=32, level=2, max_bits=None),
+    dict(c=3, H=48, W=64, level=None, max_bits=3000),
+    dict(c=3, H=37, W=53, level=2, max_bits=12345),
+    dict(c=3, H=64, W=96, level=3, max_bits=4000, q=1.0, mults=[100.0, 20.0, 20.0]),
+    dict(c=1, H=96, W=128, level=None, max_bits=9999, wavelet="bior4.4", mode="symmetric"),
+    dict(c=2, H=45, W=70, level=2, max_bits=None, wavelet="bior4.4", mode="symmetric", q=255.0, mults=[1.0, 0.2]),
+    dict(c=1, H=160, W=144, level=None, max_bits=20001, wavelet="bior6.8"),
+    dict(c=1, H=40, W=56, level=3, max_bits=777, wavelet="haar"),
+])
+def test_encode_image_decode_image_vs_oracle(oracle, cfg):
+    import spiht_amd
+    img = synth_image(2000 + cfg["H"], cfg["c"], cfg["H"], cfg["W"])
+    s = spiht_amd.SpihtSettings(wavelet=cfg.get("wavelet", "bior2.2"), quantization_scale=cfg.get("q", 50.0),
+                                mode=cfg.get("mode", "reflect"), per_channel_quant_scales=cfg.get("mults"))
+    enc = spiht_amd.encode_image(img, s, level=cfg["level"], max_bits=cfg["max_bits"])
+    ref_bytes, ref_n, ref_dec = _oracle_roundtrip(oracle, img, s, cfg["level"], cfg["max_bits"])
+    assert isinstance(enc, spiht_amd.EncodingResult)
+    assert (enc.h, enc.w, enc.c, enc.level, enc._encoding_version) == (cfg["H"], cfg["W"], cfg["c"], cfg["level"], "0.0.2")
+    assert enc.max_n == ref_n
+    assert enc.encoded_bytes == ref_bytes
+    dec = spiht_amd.decode_image(enc, s)
+    assert dec.dtype == np.float64 and dec.shape == ref_dec.shape
+    assert np.array_equal(dec, ref_dec)
+    # through the dict form (wrapper:83-89)
+    dec2 = spiht_amd.decode_image(spiht_amd.EncodingResult.from_dict(enc.to_dict()), s)
+    assert np.array_equal(dec2, dec)
+
+
+def test_decode_rec_array_and_from_rec_arr(oracle):
+    from spiht_amd.spiht_wrapper import SpihtSettings, decode_from_rec_arr, decode_rec_array, encode_image
+    img = synth_image(7, 3, 50, 41)
+    s = SpihtSettings()
+    enc = encode_image(img, s, level=2, max_bits=5000)
+    d = decode_rec_array(enc, s)
+    g = oracle.geometry(50, 41, "bior2.2", 2)
+    ref = oracle.decode(enc.encoded_bytes, enc.max_n, 3, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"])
+    assert np.array_equal(d["rec_arr"], ref)
+    assert d["spiht_metadata"] is None and (d["h"], d["w"], d["level"]) == (50, 41, 2)
+    im = decode_from_rec_arr(d["rec_arr"], 50, 41, 2, s)
+    assert np.array_equal(im, oracle.waverec2_array(oracle.dequantize(ref, 50.0), 50, 41, "bior2.2", 2))
+    with pytest.raises(NotImplementedError):
+        decode_rec_array(enc, s, return_metadata=True)
+
+
+def test_colour_model_ipt_self_consistency():
+    """parity unpinned (colour-science absent): round trip only"""
+    import spiht_amd
+    img = synth_image(3, 3, 64, 64)
+    s = spiht_amd.SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[100.0, 20.0, 20.0])
+    enc = spiht_amd.encode_image(img, s, level=3, max_bits=None)
+    dec = spiht_amd.decode_image(enc, s)
+    assert np.abs(dec - img).mean() < 0.05  # coarse quantisation of the chroma channels (scale 20)
+    with pytest.raises(ValueError):
+        spiht_amd.encode_image(img, spiht_amd.SpihtSettings(color_model="ipt"))  # case-sensitive like the reference
+
+
+def test_batch_codec_matches_single_image_path(oracle):
+    import spiht_amd
+    from spiht_amd.batch import BatchCodec
+    B, c, H, W, level, max_bits = 5, 3, 72, 88, 3, 6000
+    imgs = np.stack([synth_image(1000 + b, c, H, W) for b in range(B)])
+    imgs[3] = 0.0  # an all-zero image in the batch
+    s = spiht_amd.SpihtSettings()
+    codec = BatchCodec(c, H, W, s, level, max_bits)
+    results = codec.encode(imgs)
+    assert len(results) == B
+    for b in range(B):
+        ref_bytes, ref_n, _ = _oracle_roundtrip(oracle, imgs[b], s, level, max_bits)
+        assert results[b].encoded_bytes == ref_bytes and results[b].max_n == ref_n
+        one = spiht_amd.encode_image(imgs[b], s, level=level, max_bits=max_bits)
+        assert one.encoded_bytes == results[b].encoded_bytes
+    dec = codec.decode(results)
+    for b in range(B):
+        assert np.array_equal(dec[b], spiht_amd.decode_image(results[b], s))
+    # ragged prefixes in one decode batch (make_gif.py:46-55)
+    cut = [spiht_amd.EncodingResult(r.encoded_bytes[:k], H, W, c, r.max_n, level) for r, k in zip(results, [0, 1, 333, 750, 17])]
+    dec = codec.decode(cut)
+    for b in range(B):
+        assert np.array_equal(dec[b], spiht_amd.decode_image(cut[b], s))
+
+
+def test_config1_512_gray(oracle):
+    """BASELINE config 1 geometry: 512x512 gray, bior2.2 level 5, 0.5 bpp"""
+    import spiht_amd
+    img = synth_image(1000, 1, 512, 512)
+    s = spiht_amd.SpihtSettings()
+    mb = int(512 * 512 * 0.5)
+    enc = spiht_amd.encode_image(img, s, level=5, max_bits=mb)
+    ref_bytes, ref_n, ref_dec = _oracle_roundtrip(oracle, img, s, 5, mb)
+    assert len(enc.encoded_bytes) == 16384 and enc.encoded_bytes == ref_bytes and enc.max_n == ref_n
+    assert np.array_equal(spiht_amd.decode_image(enc, s), ref_dec)
+
+
+def test_config2_1080p_rgb(oracle):
+    """BASELINE config 2: 1920x1080 RGB, bior2.2 reflect level 7, 0.5 bpp (coefficient array 3x1111x1949, LL 13x19)"""
+    import spiht_amd
+    img = synth_image(1000, 3, 1080, 1920)
+    s = spiht_amd.SpihtSettings()
+    mb = int(1080 * 1920 * 0.5)
+    enc = spiht_amd.encode_image(img, s, level=7, max_bits=mb)
+    ref_bytes, ref_n, ref_dec = _oracle_roundtrip(oracle, img, s, 7, mb)
+    assert len(enc.encoded_bytes) == 129600
+    assert enc.max_n == ref_n and enc.encoded_bytes == ref_bytes
+    dec = spiht_amd.decode_image(enc, s)
+    assert np.array_equal(dec, ref_dec)
+    # byte prefixes of the same stream (progressive decoding)
+    for k in [1, 1000, 64800, 129599]:
+        e2 = spiht_amd.EncodingResult(enc.encoded_bytes[:k], 1080, 1920, 3, enc.max_n, 7)
+        g = oracle.geometry(1080, 1920, "bior2.2", 7)
+        r = spiht_amd.spiht_wrapper.decode_rec_array(e2, s)["rec_arr"]
+        assert np.array_equal(r, oracle.decode(e2.encoded_bytes, enc.max_n, 3, g["enc_h"], g["enc_w"], 13, 19))
+
+
+def test_config3_1024_scaled_channels_batch(oracle):
+    """BASELINE config 3 geometry: 1024x1024 RGB, level None (7), q=1 with per-channel scales [50,15,15], 0.1 bpp =
+    104857 bits (7 pad bits).  Colour conversion is a host-side pre-step and is left out here."""
+    import spiht_amd
+    from spiht_amd.batch import BatchCodec
+    s = spiht_amd.SpihtSettings(quantization_scale=1.0, per_channel_quant_scales=[50.0, 15.0, 15.0])
+    mb = int(1024 * 1024 * 0.1)
+    assert mb == 104857
+    imgs = np.stack([synth_image(1000 + b, 3, 1024, 1024) for b in range(3)])
+    codec = BatchCodec(3, 1024, 1024, s, None, mb)
+    assert (codec.geom["enc_h"], codec.geom["enc_w"], codec.geom["ll_h"], codec.geom["level"]) == (1053, 1053, 12, 7)
+    res = codec.encode(imgs)
+    dec = codec.decode(res)
+    for b in range(3):
+        assert len(res[b].encoded_bytes) == 13108
+        if b != 1:
+            continue  # one full oracle comparison keeps the test short
+        ref_bytes, ref_n, ref_dec = _oracle_roundtrip(oracle, imgs[b], s, None, mb)
+        assert res[b].encoded_bytes == ref_bytes and res[b].max_n == ref_n
+        assert np.array_equal(dec[b], ref_dec)
+
+
+def test_config5_4096_bior68_bpp_sweep(oracle):
+    """BASELINE config 5: 4096x4096 RGB, bior6.8 reflect, level 9 (above pywt's max level 7), bpp sweep.
+    The code is embedded: every budget's stream is a bit prefix of the largest one, so one oracle encode pins all
+    four; the decoder is checked against the oracle on each stream."""
+    import spiht_amd
+    img = synth_image(1000, 3, 4096, 4096)
+    s = spiht_amd.SpihtSettings(wavelet="bior6.8")
+    g = oracle.geometry(4096, 4096, "bior6.8", 9)
+    assert (g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"]) == (4241, 4241, 24, 24)
+    budgets = [int(4096 * 4096 * bpp) for bpp in (0.075, 0.1, 0.5, 1.0)]
+    assert budgets == [1258291, 1677721, 8388608, 16777216]
+    ref_bytes, ref_n, _ = oracle.encode_image(img, "bior6.8", "reflect", 9, 50.0, None, budgets[-1])
+    ref_bits = oracle.bytes_to_bits(ref_bytes)
+    for mb in budgets:
+        enc = spiht_amd.encode_image(img, s, level=9, max_bits=mb)
+        assert enc.max_n == ref_n and len(enc.encoded_bytes) == (mb + 7) // 8
+        bits = oracle.bytes_to_bits(enc.encoded_bytes)
+        assert np.array_equal(bits[:mb], ref_bits[:mb]) and not bits[mb:].any()
+        rec = spiht_amd.spiht_wrapper.decode_rec_array(enc, s)["rec_arr"]
+        assert np.array_equal(rec, oracle.decode(enc.encoded_bytes, enc.max_n, 3, 4241, 4241, 24, 24))
+        if mb == budgets[1]:
+            dec = spiht_amd.decode_image(enc, s)
+            ref = oracle.waverec2_array(oracle.dequantize(rec, 50.0), 4096, 4096, "bior6.8", 9)
+            assert np.array_equal(dec, ref)
+            assert np.abs(dec - img).mean() < 0.1
