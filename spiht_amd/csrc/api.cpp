@@ -333,6 +333,7 @@ extern "C" int spiht_ctx_create(int device, spiht_ctx **out) {
     for (int s = 0; s < ST_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
     int rc = ensure(ctx, ctx->err, 256);
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
+    (void)hipMemset(ctx->err.p, 0, 256);
     *out = ctx;
     return SPIHT_OK;
 }
@@ -352,11 +353,20 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     delete ctx;
 }
 
+static int read_err(spiht_ctx *ctx);
+static int clear_err(spiht_ctx *ctx);
+// Waits for the context's stream and reports (then clears) what the device-side guards of the batched calls
+// queued since the last synchronize recorded.
 extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
     if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return SPIHT_OK;
+    int st = read_err(ctx);  // includes the stream synchronize
+    if (st != SPIHT_OK) {
+        (void)clear_err(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    return st;
 }
 extern "C" int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled) {
     if (!ctx) return SPIHT_ERR_ARG;
@@ -649,14 +659,13 @@ extern "C" int spiht_encode_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_
     if (B == 0) return SPIHT_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(clear_err(ctx));
     const int chunk = batch_chunk(g);
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         CHK(encode_device(ctx, g, d_x + (size_t)b0 * g.n, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride,
                           d_nbits + b0, d_max_n + b0));
     }
-    return read_err(ctx);
+    return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
 
 extern "C" int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
@@ -668,9 +677,8 @@ extern "C" int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uin
     if (B == 0) return SPIHT_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(clear_err(ctx));
     CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out));
-    return read_err(ctx);
+    return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
 
 extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
@@ -900,7 +908,6 @@ extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img,
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(clear_err(ctx));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
     const int chunk = batch_chunk(g);
@@ -918,7 +925,7 @@ extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img,
         CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
                           d_max_n + b0, true));
     }
-    return read_err(ctx);
+    return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
 
 extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
@@ -934,7 +941,6 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(clear_err(ctx));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
     const int chunk = batch_chunk(g);
@@ -949,7 +955,7 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
         CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
                         d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
     }
-    return read_err(ctx);
+    return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
 
 extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes) {

@@ -79,8 +79,11 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NR = 2 * DW_TH + F - 2;  // input rows needed
     constexpr int HC = (NC + 1) / 2;       // columns per parity plane
     static_assert(NC <= DW_BLOCK, "one thread per input column");
-    __shared__ double s_lo[2][DW_TH][HC + 1];
-    __shared__ double s_hi[2][DW_TH][HC + 1];
+    // two column-parity planes; the +8 makes the plane stride an odd multiple of 16 banks, so the even and odd lanes
+    // of one ds_write_b64 lane group land on different banks
+    constexpr int RS = HC + 1, PS = DW_TH * RS + 8;
+    __shared__ double s_lo[2][PS];
+    __shared__ double s_hi[2][PS];
     __shared__ int s_row[NR];
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
@@ -113,8 +116,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
                 if ((LOM >> j) & 1u) sl += a.lo[j] * x[2 * o + F - 1 - j];
                 if ((HIM >> j) & 1u) shh += a.hi[j] * x[2 * o + F - 1 - j];
             }
-            s_lo[par][o][hc] = sl;
-            s_hi[par][o][hc] = shh;
+            s_lo[par][o * RS + hc] = sl;
+            s_hi[par][o * RS + hc] = shh;
         }
     }
     __syncthreads();
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
         double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
 #pragma unroll
         for (int j = 0; j < F; j++) {
-            const double vl = s_lo[(F - 1 - j) & 1][o][wcol + ((F - 1 - j) >> 1)];
-            const double vh = s_hi[(F - 1 - j) & 1][o][wcol + ((F - 1 - j) >> 1)];
+            const double vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+            const double vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
             if ((LOM >> j) & 1u) { aa += a.lo[j] * vl; da += a.lo[j] * vh; }
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }

@@ -158,6 +158,7 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
             ctx.handle, C.c_void_p(d_img), 1, c, h, w, wid, mid, -1 if level is None else int(level),
             float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(d_out), slot,
             C.c_void_p(d_meta), C.c_void_p(d_meta + 8), None))
+        ctx.synchronize()  # the batched entry points only queue work; device-side guards report here
         meta = np.zeros(2, dtype=np.uint64)
         ctx.download(meta, d_meta)
         nbits = int(meta[0])
@@ -223,6 +224,7 @@ def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settin
         _lib.check(L.spiht_dequant_idwt_batch_f64(ctx.handle, C.c_void_p(d_rec), 1, c, h, w, wid, mid,
                                                   -1 if level is None else int(level),
                                                   float(spiht_settings.quantization_scale), mults_p, C.c_void_p(d_out)))
+        ctx.synchronize()
         ctx.download(out, d_out)
     finally:
         ctx.free(d_rec)
