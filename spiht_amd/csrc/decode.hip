@@ -77,7 +77,17 @@ struct Chain {  // running list lengths after item k; seq == k+1 once item k pub
     uint32_t lsp, lip, nxt, ret;
 };
 
+struct LipItem {  // one LIP-pass window, produced by the parallel window scan
+    uint64_t lo;
+    uint32_t Wb, e_start, m_rem, b_lsp, b_lip;
+    uint32_t flags;  // pos0 | cin << 8 | hibit0 << 9 | valid << 10
+};
+
 struct DecShared {
+    LipItem lipq[DEC_NW * 64];
+    uint64_t wpart[DEC_NW];     // per-wave partials of the block scans
+    uint32_t wfun[DEC_NW];      // per-wave carry functions
+    uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     Slot ring[DEC_RING];
     Chain chain[DEC_RING];
     uint32_t head;              // items produced so far
@@ -162,7 +172,26 @@ __device__ __forceinline__ uint64_t lip_starts(uint64_t W, uint32_t pos, uint32_
     return S;
 }
 
-// What a LIP window contains, as a function of the item fields only: sequencer and worker both call it.
+// position of the k-th (0-based) set bit of x; needs popcount(x) > k
+__device__ __forceinline__ uint32_t select64(uint64_t x, uint32_t k) {
+    uint32_t r = 0;
+    uint32_t c = (uint32_t)__popc((uint32_t)x);
+    if (k >= c) { k -= c; x >>= 32; r = 32; }
+    uint32_t y = (uint32_t)x;
+    c = (uint32_t)__popc(y & 0xFFFFu);
+    if (k >= c) { k -= c; y >>= 16; r += 16; }
+    c = (uint32_t)__popc(y & 0xFFu);
+    if (k >= c) { k -= c; y >>= 8; r += 8; }
+    c = (uint32_t)__popc(y & 0xFu);
+    if (k >= c) { k -= c; y >>= 4; r += 4; }
+    c = (uint32_t)__popc(y & 0x3u);
+    if (k >= c) { k -= c; y >>= 2; r += 2; }
+    if (k >= (y & 1u)) r += 1;
+    return r;
+}
+
+// What a LIP window contains, as a function of the item fields only (no cross-lane operation): the parallel
+// window scan (one window per lane) and the per-window work (one window per wavefront) both call it.
 struct LipWin {
     uint64_t S_in;     // token starts that belong to the pass and are complete
     uint64_t sig;      // those of them that are significant ('1 s')
@@ -182,11 +211,9 @@ __device__ __forceinline__ LipWin lip_window(uint64_t lo, uint32_t Wb, uint32_t 
     r.ends = cnt > m_rem;
     r.pos1 = 64;
     if (r.ends) {
-        // position of token start number m_rem (the first one that is NOT part of the pass)
-        const uint32_t lane = threadIdx.x & 63u;
-        const bool isS = (S >> lane) & 1ull;
-        const uint64_t pm = __ballot(isS && mbcnt(S) == m_rem);
-        r.pos1 = (uint32_t)__builtin_ctzll(pm);
+        // position of token start number m_rem (the first one that is NOT part of the pass); no cross-lane
+        // operation here: this function also runs with one window per lane
+        r.pos1 = select64(S, m_rem);
         S &= (1ull << r.pos1) - 1ull;
     }
     r.ntok = r.ends ? m_rem : cnt;
@@ -237,6 +264,35 @@ __device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t 
     const uint32_t k = widx - rc.base64;
     lo = readlane64(rc.v, k);
     hi = readlane64(rc.v, k + 1);
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = (uint32_t)__shfl_up((int)lo, o);
+    hi = (uint32_t)__shfl_up((int)hi, o);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// exclusive prefix sum of a packed 64-bit value over the whole workgroup (two barriers)
+__device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint64_t &total, uint32_t wave, uint32_t lane) {
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t t = shfl_up_u64(inc, o);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    if (lane == 63) sh.wpart[wave] = inc;
+    __syncthreads();
+    uint64_t pre = 0, tot = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < DEC_NW; w++) {
+        const uint64_t pw = sh.wpart[w];
+        if (w < wave) pre += pw;
+        tot += pw;
+    }
+    __syncthreads();
+    total = tot;
+    return pre + inc - v;
 }
 
 // ---- sequencer side of the ring ----
@@ -580,61 +636,127 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         if (lip_len > a.caps.lip || lis_len > a.caps.lis) bad = true;
         __syncthreads();
 
+        // the sequencer is the serial chain of the whole image: when other kernels (or other images' workers) share
+        // its SIMD it must not queue for issue slots behind them
+        if (wave == 0) __builtin_amdgcn_s_setprio(3);
         bool done = bad;
         for (; !done; --n) {
             const uint32_t lsp_len0 = lsp_len;
             const int32_t base_val = (n == 0) ? 1 : (int32_t)((1u << (n - 1)) + (1u << n));  // :364-370
 
             // ================= LIP pass (encoder_decoder.rs:355-377) =================
+            // No sequencer here: the only serial dependence between 64-bit windows is one carry bit (does the window
+            // start on a pending sign bit?), so DEC_NW*64 windows are scanned at once, one per lane: both carry-in
+            // hypotheses per window, a block scan of the carry functions, then block scans of the token / LSP / LIP
+            // counts give every window its exact list offsets; afterwards each wavefront works through its 64 windows.
             {
-                const uint32_t par = phase & 1u;
                 PF_ADD(7);
-                if (wave == 0) {
-                    uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0, lsp_l = lsp_len, dn = 0;
-                    while (m_rem > 0) {
-                        if (P >= nbits) { dn = 1; break; }
-                        const uint32_t widx = P >> 6, pos = P & 63u, Wb = widx << 6;
-                        uint64_t lo, hi;
-                        window(bs, rc, widx, lane, lo, hi);
-                        const LipWin lw = lip_window(lo, Wb, pos, cin, m_rem, nbits);
-                        const uint32_t nsig = (uint32_t)__popcll(lw.sig);
-                        const uint32_t nnon = (uint32_t)__popcll(lw.S_in & ~lw.sig);
-                        if (lsp_l + nsig > a.caps.lsp) { if (lane == 0) sh.bad = 1; dn = 1; break; }
-                        Item it;
-                        it.kind = 0; it.Wb = Wb; it.pos0 = pos; it.pos1 = lw.pos1; it.e_start = tok_base; it.cin = cin;
-                        it.m_rem = m_rem; it.first = 1; it.b_lsp = lsp_l; it.b_lip = lipn_len; it.b_nxt = 0; it.b_ret = 0;
-                        it.lo = lo; it.hi = hi; it.fm = 0;
-                        seq_publish(sh, seq, it, lane);
-                        lsp_l += nsig;
-                        lipn_len += nnon;
-                        if (lw.trunc) { dn = 1; cin = 0; break; }
-                        if (lw.ends) {
-                            P = Wb + lw.pos1;
-                            m_rem = 0;
-                            cin = 0;
-                        } else {
-                            m_rem -= lw.ntok;
-                            tok_base += lw.ntok;
-                            P = Wb + 64;
-                            cin = lw.cout;
+                uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0, lsp_l = lsp_len;
+                bool dn = false;
+                while (m_rem > 0 && !dn) {
+                    if (P >= nbits) { dn = true; break; }
+                    const uint32_t widx0 = P >> 6, gw = wave * 64 + lane;
+                    const uint32_t widx = widx0 + gw, Wb = widx << 6;
+                    const uint32_t pos = gw == 0 ? (P & 63u) : 0u;
+                    const uint64_t lo = (uint64_t)stream_word(bs, 2 * widx) | ((uint64_t)stream_word(bs, 2 * widx + 1) << 32);
+                    const uint32_t hb = stream_word(bs, 2 * widx + 2) & 1u;
+                    // carry function of this window: cout for cin = 0 and for cin = 1 (window 0's cin is known)
+                    uint32_t c0, c1;
+                    (void)lip_starts(lo, pos, 0, c0);
+                    (void)lip_starts(lo, pos, 1, c1);
+                    if (gw == 0) { if (cin) c0 = c1; else c1 = c0; }
+                    uint32_t F = c0 | (c1 << 1);  // bit x = cout when cin = x
+                    // inclusive scan of function composition along the lanes (H = G after F: H(x) = G(F(x)))
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t Fp = (uint32_t)__shfl_up((int)F, o);
+                        if (lane >= (uint32_t)o) F = ((F >> (Fp & 1u)) & 1u) | (((F >> ((Fp >> 1) & 1u)) & 1u) << 1);
+                    }
+                    if (lane == 63) sh.wfun[wave] = F;
+                    __syncthreads();
+                    uint32_t wcin = cin;  // carry into this wave's first window
+                    for (uint32_t w = 0; w < wave; w++) wcin = (sh.wfun[w] >> wcin) & 1u;
+                    uint32_t Fprev = (uint32_t)__shfl_up((int)F, 1);
+                    const uint32_t my_cin = lane == 0 ? wcin : ((Fprev >> wcin) & 1u);
+                    const uint32_t my_cout = (F >> wcin) & 1u;
+                    // tokens that start in this window (stream end respected), then their prefix over the block
+                    uint32_t cdummy;
+                    uint64_t S = lip_starts(lo, pos, my_cin, cdummy);
+                    const uint32_t vb = Wb >= nbits ? 0u : ((nbits - Wb) < 64u ? (nbits - Wb) : 64u);
+                    if (vb < 64) S &= vb ? ((1ull << vb) - 1ull) : 0ull;
+                    const uint32_t cnt = (uint32_t)__popcll(S);
+                    uint64_t tot1;
+                    const uint64_t ex1 = block_exscan(sh, (uint64_t)cnt, tot1, wave, lane);
+                    const uint32_t before = (uint32_t)ex1;
+                    const uint32_t m_here = m_rem > before ? m_rem - before : 0u;
+                    const bool in_pass = m_here > 0 && vb > 0;
+                    LipWin lw;
+                    lw.S_in = 0; lw.sig = 0; lw.ntok = 0; lw.trunc = 0; lw.ends = 0; lw.pos1 = 64; lw.cout = 0;
+                    if (in_pass) lw = lip_window(lo, Wb, pos, my_cin, m_here, nbits);
+                    const uint32_t nsig = (uint32_t)__popcll(lw.sig);
+                    const uint32_t nnon = (uint32_t)__popcll(lw.S_in & ~lw.sig);
+                    uint64_t tot2;
+                    const uint64_t ex2 = block_exscan(sh, (uint64_t)nsig | ((uint64_t)nnon << 20) | ((uint64_t)lw.ntok << 40), tot2,
+                                                      wave, lane);
+                    {
+                        LipItem &q = sh.lipq[gw];
+                        q.lo = lo; q.Wb = Wb; q.e_start = tok_base + before; q.m_rem = m_here;
+                        q.b_lsp = lsp_l + ((uint32_t)ex2 & 0xFFFFFu);
+                        q.b_lip = lipn_len + ((uint32_t)(ex2 >> 20) & 0xFFFFFu);
+                        q.flags = pos | (my_cin << 8) | (hb << 9) | ((in_pass ? 1u : 0u) << 10);
+                    }
+                    if (threadIdx.x == 0) sh.lp_end[0] = 0;
+                    __syncthreads();
+                    if (in_pass && (lw.ends || lw.trunc)) {  // at most one window
+                        sh.lp_end[0] = lw.trunc ? 2u : 1u;
+                        sh.lp_end[1] = Wb + lw.pos1;
+                    } else if (in_pass && lw.ntok > 0 && before + lw.ntok == m_rem) {
+                        // the pass completes exactly with this window's last token (whose sign bit may be the next
+                        // window's bit 0: carried in lp_end[3])
+                        sh.lp_end[0] = 3u;
+                        sh.lp_end[1] = Wb + 64;
+                        sh.lp_end[3] = my_cout;
+                    }
+                    if (gw == DEC_NW * 64 - 1) sh.lp_end[2] = my_cout;
+                    const uint32_t t_sig = (uint32_t)tot2 & 0xFFFFFu, t_non = (uint32_t)(tot2 >> 20) & 0xFFFFFu;
+                    const uint32_t t_tok = (uint32_t)(tot2 >> 40);
+                    if (lsp_l + t_sig > a.caps.lsp && threadIdx.x == 0) sh.bad = 1;
+                    __syncthreads();
+                    // ---- per-window work ----
+                    if (!sh.bad) {
+                        for (uint32_t qn = wave; qn < DEC_NW * 64; qn += DEC_NW) {  // round robin: short passes use all waves
+                            const LipItem q = sh.lipq[qn];
+                            if (!((q.flags >> 10) & 1u)) break;  // windows of a pass are contiguous
+                            Item it;
+                            it.kind = 0; it.Wb = q.Wb; it.pos0 = q.flags & 0xFFu; it.pos1 = 64; it.e_start = q.e_start;
+                            it.cin = (q.flags >> 8) & 1u; it.m_rem = q.m_rem; it.first = 1; it.b_lsp = q.b_lsp; it.b_lip = q.b_lip;
+                            it.b_nxt = 0; it.b_ret = 0; it.lo = q.lo; it.hi = (q.flags >> 9) & 1u; it.fm = 0;
+                            work_lip(sh, a, it, lip, lipn, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
                         }
                     }
-                    if (cin) P += 1;
-                    seq_close(sh, par, seq, P, dn, lsp_l, lipn_len, lane);
-                } else {
-                    worker_phase(sh, a, g, myk, par, lip, lipn, nullptr, nullptr, nullptr, nullptr, lsp_idx, lsp_val, nbits,
-                                 tail_start, n, base_val, wave - 1, lane);
+                    // ---- advance (every wave computes the same) ----
+                    lsp_l += t_sig;
+                    lipn_len += t_non;
+                    const uint32_t endk = sh.lp_end[0];
+                    if (endk == 2) { dn = true; cin = 0; }
+                    else if (endk == 1) { P = sh.lp_end[1]; m_rem = 0; cin = 0; }
+                    else if (endk == 3) { P = sh.lp_end[1]; m_rem = 0; cin = sh.lp_end[3]; }
+                    else {
+                        m_rem -= t_tok;
+                        tok_base += t_tok;
+                        P = (widx0 + DEC_NW * 64) << 6;
+                        cin = sh.lp_end[2];
+                    }
+                    if (sh.bad) dn = true;
+                    __syncthreads();
                 }
-                PF_ADD(0);
-                __syncthreads();
-                phase++;
-                P = sh.r_P; lsp_len = sh.r_lsp; lip_len = sh.r_lip;
-                if (sh.r_done || sh.bad) done = true;
-                PF_CNT(5, sh.head - seq);
-                seq = sh.head;
+                if (cin && !dn) P += 1;
+                lsp_len = lsp_l;
+                lip_len = lipn_len;
+                if (dn) done = true;
                 { uint32_t *t = lip; lip = lipn; lipn = t; }
                 __syncthreads();
-                PF_ADD(1);
+                PF_ADD(0);
             }
             if (done) break;
 
@@ -708,47 +830,46 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             } while (pos < vb && rel < nEw);
 #else
                             // The same loop, hand-scheduled: this serial chain bounds the whole decoder and hipcc's
-                            // version of it is twice as long (uniform conditions routed through VCC/EXEC).  All scalar:
-                            // s_and sets SCC (= candidate exists); five SALU instructions separate s_ff1 from the
-                            // v_readlane that uses its result as lane select (4 wait states needed).
+                            // version of it is more than twice as long (uniform conditions routed through VCC/EXEC).
+                            // Relative coordinates keep the dependent chain short: L = bits from the current position on,
+                            // T = type mask from the current entry on, so a candidate is `L & T` (s_and sets SCC), its
+                            // offset d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (two shifts each: a single shift
+                            // count must stay below 64).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and.
+                            // Four SALU instructions separate the s_add that makes the lane select from v_readlane.
                             {
-                                uint64_t t64;
                                 uint32_t f, dd, len;
                                 // tell the compiler these wave-uniform values live in SGPRs
                                 rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
                                 pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                                const uint32_t vb_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)vb);
-                                const uint32_t nEw_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)nEw);
+                                uint64_t Lr = lo >> pos, Tr = TA >> rel, c64;
                                 asm volatile(
+                                    "s_and_b64 %[c], %[L], %[T]\n\t"
+                                    "s_cbranch_scc0 s_hop_done%=\n"
                                     "s_hop_loop%=:\n\t"
-                                    "s_lshr_b64 %[t], %[TA], %[rel]\n\t"
-                                    "s_lshl_b64 %[t], %[t], %[pos]\n\t"
-                                    "s_and_b64 %[t], %[t], %[lo]\n\t"
-                                    "s_cbranch_scc0 s_hop_none%=\n\t"
-                                    "s_ff1_i32_b64 %[f], %[t]\n\t"
+                                    "s_ff1_i32_b64 %[d], %[c]\n\t"
+                                    "s_add_i32 %[f], %[pos], %[d]\n\t"
+                                    "s_lshr_b64 %[T], %[T], %[d]\n\t"
+                                    "s_lshr_b64 %[L], %[L], %[d]\n\t"
                                     "s_bitset1_b64 %[fm], %[f]\n\t"
-                                    "s_sub_i32 %[d], %[f], %[pos]\n\t"
+                                    "s_lshr_b64 %[T], %[T], 1\n\t"
+                                    "v_readlane_b32 %[len], %[LAv], %[f]\n\t"
                                     "s_add_i32 %[rel], %[rel], %[d]\n\t"
                                     "s_add_i32 %[rel], %[rel], 1\n\t"
-                                    "s_nop 0\n\t"
-                                    "v_readlane_b32 %[len], %[LAv], %[f]\n\t"
+                                    "s_lshr_b64 %[L], %[L], %[len]\n\t"
                                     "s_add_i32 %[pos], %[f], %[len]\n\t"
-                                    "s_cmp_lt_u32 %[pos], %[vb]\n\t"
-                                    "s_cbranch_scc0 s_hop_done%=\n\t"
-                                    "s_cmp_lt_u32 %[rel], %[nEw]\n\t"
-                                    "s_cbranch_scc1 s_hop_loop%=\n\t"
-                                    "s_branch s_hop_done%=\n"
-                                    "s_hop_none%=:\n\t"
-                                    "s_sub_i32 %[d], %[vb], %[pos]\n\t"
-                                    "s_sub_i32 %[f], %[nEw], %[rel]\n\t"
-                                    "s_min_u32 %[d], %[d], %[f]\n\t"
-                                    "s_add_i32 %[rel], %[rel], %[d]\n\t"
-                                    "s_add_i32 %[pos], %[pos], %[d]\n"
+                                    "s_and_b64 %[c], %[L], %[T]\n\t"
+                                    "s_cbranch_scc1 s_hop_loop%=\n"
                                     "s_hop_done%=:\n\t"
-                                    : [rel] "+s"(rel), [pos] "+s"(pos), [fm] "+s"(fm), [t] "=&s"(t64), [f] "=&s"(f), [d] "=&s"(dd),
-                                      [len] "=&s"(len)
-                                    : [TA] "s"(TA), [lo] "s"(lo), [vb] "s"(vb_s), [nEw] "s"(nEw_s), [LAv] "v"(LAv)
+                                    : [rel] "+s"(rel), [pos] "+s"(pos), [fm] "+s"(fm), [L] "+s"(Lr), [T] "+s"(Tr), [c] "=&s"(c64),
+                                      [f] "=&s"(f), [d] "=&s"(dd), [len] "=&s"(len)
+                                    : [LAv] "v"(LAv)
                                     : "scc");
+                                // no candidate left among this chunk's entries / this window's bits: the rest take one bit each
+                                if (pos < vb) {
+                                    const uint32_t z = (vb - pos) < (nEw - rel) ? (vb - pos) : (nEw - rel);
+                                    rel += z;
+                                    pos += z;
+                                }
                             }
 #endif
                             i = Ebase + rel;
