@@ -178,3 +178,65 @@ def test_config5_4096_bior68_bpp_sweep(oracle):
             ref = oracle.waverec2_array(oracle.dequantize(rec, 50.0), 4096, 4096, "bior6.8", 9)
             assert np.array_equal(dec, ref)
             assert np.abs(dec - img).mean() < 0.1
+
+
+def test_more_images_than_slots(oracle):
+    """B larger than the number of list-scratch slots: every workgroup codes several images in turn (the
+    encoder has <= 256 slots, the decoder <= 2048)."""
+    import spiht_amd
+    from spiht_amd.batch import BatchCodec
+    B, c, H, W, level, max_bits = 2300, 1, 16, 24, 1, 700
+    rng = np.random.default_rng(1)
+    imgs = rng.integers(0, 256, (B, c, H, W)).astype(np.float64) / 255
+    imgs[7] = 0.0
+    s = spiht_amd.SpihtSettings()
+    codec = BatchCodec(c, H, W, s, level, max_bits)
+    res = codec.encode(imgs)
+    dec = codec.decode(res)
+    for b in list(range(0, B, 97)) + [7, 255, 256, 257, 2047, 2048, 2049, B - 1]:
+        ref_bytes, ref_n, ref_dec = _oracle_roundtrip(oracle, imgs[b], s, level, max_bits)
+        assert res[b].encoded_bytes == ref_bytes and res[b].max_n == ref_n, b
+        assert np.array_equal(dec[b], ref_dec), b
+
+
+def test_raw_batch_entry_points(oracle):
+    """spiht_encode_batch_i32 / spiht_decode_batch_i32 / spiht_pyramid_batch_i32 on device buffers"""
+    import ctypes as C
+    from conftest import synth_coeffs
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    ctx, L = _lib.default_context(), _lib.lib()
+    B, c, h, w, lh, lw, mb = 6, 3, 37, 53, 5, 7, 3001
+    xs = np.stack([synth_coeffs(50 + b, c, h, w, lh, lw, scale=800.0) for b in range(B)])
+    slot = ((mb + 7) // 8 + 3) & ~3
+    d_x = DeviceArray(ctx, xs.shape, np.int32)
+    d_out = DeviceArray(ctx, (B, slot), np.uint8)
+    d_nbits = DeviceArray(ctx, (B,), np.uint64)
+    d_nbytes = DeviceArray(ctx, (B,), np.uint64)
+    d_maxn = DeviceArray(ctx, (B,), np.uint8)
+    d_rec = DeviceArray(ctx, xs.shape, np.int32)
+    d_dm = DeviceArray(ctx, xs.shape, np.uint8)
+    d_lm = DeviceArray(ctx, xs.shape, np.uint8)
+    d_mx = DeviceArray(ctx, (B,), np.uint32)
+    vp = C.c_void_p
+    d_x.upload(xs)
+    _lib.check(L.spiht_encode_batch_i32(ctx.handle, vp(d_x.ptr), B, c, h, w, lh, lw, mb, vp(d_out.ptr), slot, vp(d_nbits.ptr),
+                                        vp(d_maxn.ptr)))
+    _lib.check(L.spiht_nbits_to_nbytes(ctx.handle, vp(d_nbits.ptr), B, vp(d_nbytes.ptr)))
+    _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), slot, vp(d_nbytes.ptr), vp(d_maxn.ptr), B, c, h, w, lh, lw,
+                                        vp(d_rec.ptr)))
+    _lib.check(L.spiht_pyramid_batch_i32(ctx.handle, vp(d_x.ptr), B, c, h, w, lh, lw, vp(d_dm.ptr), vp(d_lm.ptr), vp(d_mx.ptr)))
+    ctx.synchronize()
+    out, nbits, maxn, rec, mx = d_out.download(), d_nbits.download(), d_maxn.download(), d_rec.download(), d_mx.download()
+    for b in range(B):
+        ref, ref_n, ref_nb = oracle.encode_nbits(xs[b], lh, lw, mb)
+        assert int(nbits[b]) == ref_nb and int(maxn[b]) == ref_n
+        assert out[b, :(ref_nb + 7) // 8].tobytes() == ref and not out[b, (ref_nb + 7) // 8:].any()
+        assert np.array_equal(rec[b], oracle.decode(ref, ref_n, c, h, w, lh, lw))
+        assert int(mx[b]) == int(np.abs(xs[b]).max())
+    # a too-small slot is reported by synchronize(), not silently truncated
+    _lib.check(L.spiht_encode_batch_i32(ctx.handle, vp(d_x.ptr), B, c, h, w, lh, lw, 10 ** 9, vp(d_out.ptr), slot, vp(d_nbits.ptr),
+                                        vp(d_maxn.ptr)))
+    with pytest.raises(ValueError):
+        ctx.synchronize()
+    ctx.synchronize()  # the error word was cleared
