@@ -197,6 +197,29 @@ def main():
         ms_l1, n_l1 = stages.get("dwt_level1", (0.0, 0))
         avg_ms = ms_l1 / n_l1 if n_l1 else float("nan")
         achieved = dwt_bytes / (avg_ms * 1e-3) / 1e9 if n_l1 else float("nan")
+        # HBM traffic of that kernel from PMC counters (tools/collect_traffic.py; separate rocprofv3 --pmc passes)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "dwt_l1_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = round(json.load(open(tpath))["hbm_bytes_per_image"] * per_launch)
+            except Exception:
+                traffic = None
+        # latency of ONE image (BASELINE config 2 as written: "single 1920x1080 RGB"), HBM-resident, same kernels
+        t_enc, t_dec = [], []
+        for _ in range(5):
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            codec.encode_device(d_img.ptr, 1, out_ptr, nbits_ptr, maxn_ptr)
+            ctx.synchronize()
+            t2 = time.perf_counter()
+            codec.nbits_to_nbytes(nbits_ptr, 1, d_nbytes.ptr)
+            codec.decode_device(out_ptr, d_nbytes.ptr, maxn_ptr, 1, d_rec_img.ptr)
+            ctx.synchronize()
+            t3 = time.perf_counter()
+            t_enc.append((t2 - t1) * 1e3)
+            t_dec.append((t3 - t2) * 1e3)
+        single = {"encode_ms": round(sorted(t_enc)[2], 3), "decode_ms": round(sorted(t_dec)[2], 3)}
         result = {
             "metric": "Mpixels/sec encode+decode at fixed bpp; bitstream-exact vs Rust ref",
             "value": round(mpix, 2),
@@ -216,9 +239,10 @@ def main():
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]]},
             "roofline": {"bound": "hbm", "kernel": "k_dwt_level<6> (forward DWT level 1, fused quantise)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4)},
             "stages_ms_per_step_summed_over_streams": {k: round(v[0] / args.steps, 3) for k, v in stages.items() if v[1]},
+            "single_image_latency": single,
             "check": {"nbits_all_equal_budget": bool((nbits == max_bits).all()), "max_n": int(maxn[0]),
                       "mean_abs_err_image0": round(mae, 5), "gather_rows_match": gather_ok},
         }
