@@ -51,6 +51,10 @@ int spiht_ctx_create(int device, spiht_ctx **out);
 void spiht_ctx_destroy(spiht_ctx *ctx);
 /* Block until everything queued on the context's stream has finished. */
 int spiht_ctx_synchronize(spiht_ctx *ctx);
+/* Order across contexts without blocking the host: everything queued on `ctx` after this call waits (on the
+ * device) for everything queued on `other` before it.  Lets one context's stream encode step i+1 while another
+ * decodes step i. */
+int spiht_ctx_wait_on(spiht_ctx *ctx, spiht_ctx *other);
 /* Stage timing: when enabled, HIP events bracket each kernel group of the next calls
  * (on the context's own stream); spiht_ctx_get_timing returns accumulated ms and launches. */
 int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled);

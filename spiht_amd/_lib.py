@@ -33,7 +33,7 @@ _lib_lock = threading.Lock()
 # every symbol include/spiht_hip.h declares
 SYMBOLS = [
     "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
-    "spiht_ctx_synchronize", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
+    "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
     "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
     "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
@@ -65,6 +65,7 @@ def lib():
         L.spiht_ctx_destroy.argtypes = [vp]
         L.spiht_ctx_destroy.restype = None
         L.spiht_ctx_synchronize.argtypes = [vp]
+        L.spiht_ctx_wait_on.argtypes = [vp, vp]
         L.spiht_ctx_set_timing.argtypes = [vp, i32]
         L.spiht_ctx_reset_timing.argtypes = [vp]
         L.spiht_ctx_stage_name.restype = C.c_char_p
@@ -133,6 +134,10 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def wait_on(self, other):
+        """device-side ordering: work queued on self after this call waits for work queued on `other` before it"""
+        check(self._lib.spiht_ctx_wait_on(self.handle, other.handle))
 
     def synchronize(self):
         check(self._lib.spiht_ctx_synchronize(self.handle))

@@ -368,6 +368,18 @@ extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
     }
     return st;
 }
+extern "C" int spiht_ctx_wait_on(spiht_ctx *ctx, spiht_ctx *other) {
+    if (!ctx || !other || ctx->device != other->device) return SPIHT_ERR_ARG;
+    if (ctx == other) return SPIHT_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    hipEvent_t ev;
+    HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e1 = hipEventRecord(ev, other->stream);
+    hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(ctx->stream, ev, 0) : e1;
+    (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+    HIPCHK(e2);
+    return SPIHT_OK;
+}
 extern "C" int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled) {
     if (!ctx) return SPIHT_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);

@@ -22,6 +22,7 @@
 // so GPU and oracle agree bit for bit and both agree with pywt to a few ulp.
 // HBM-bound: per level, 8 B per input sample + 8 B (LL) + 3*4 B (details) per output position.
 #include "common.h"
+#include <stdlib.h>
 
 #define DW_TH 16      // output rows per tile
 #define DW_TW 64      // output cols per tile
@@ -156,6 +157,108 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;               // 'da' bottom-left
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
         amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+
+// ---- row-marching variant of the forward level ------------------------------------------------------------------
+// A workgroup owns a strip of MW_SW output columns and marches down MW_ROWS output rows: thread = input column keeps
+// the F rows its column filter needs in registers (two new rows per step, prefetched MW_PF steps ahead, so every
+// input sample is loaded exactly once per strip), the low/high outputs of the step go through a double-buffered LDS
+// row to the axis -1 filter: threads 0..127 produce (aa, ad) from the low row, threads 128..255 (da, dd) from the
+// high row.  One barrier per output row; loads are a continuous stream with no vertical halo.
+#define MW_PF 8      // steps of look-ahead for the two rows a step loads
+#define MW_ROWS 136  // output rows per workgroup
+template <int F, uint32_t LOM, uint32_t HIM>
+__global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint32_t gy) {
+    constexpr int SW = (256 - (F - 2)) / 2;  // output columns per strip: exactly 256 input columns
+    constexpr int HC = 128 + 2;
+    __shared__ double s_lo[2][2][HC];        // [step parity][column parity][column >> 1]
+    __shared__ double s_hi[2][2][HC];
+    uint32_t tbx, tby, tbz;
+    xcd_tile(gx, gy, a.planes, tbx, tby, tbz);
+    const int plane = (int)tbz;
+    const int ow0 = (int)tbx * SW, oa = (int)tby * MW_ROWS;
+    const int ob = min(oa + MW_ROWS, a.out_h);
+    const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
+    const int tid = threadIdx.x;
+    const int gc = ext_index(2 * ow0 + 2 - F + tid, a.in_w, a.mode);
+    auto ld = [&](int r) -> double {
+        const int gr = ext_index(r, a.in_h, a.mode);
+        return (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
+    };
+    // window: rows 2o+2-F .. 2o+1 of output row o
+    double win[F];
+#pragma unroll
+    for (int t = 0; t < F; t++) win[t] = ld(2 * oa + 2 - F + t);
+    double pq[MW_PF][2];
+#pragma unroll
+    for (int u = 0; u < MW_PF; u++) { pq[u][0] = ld(2 * (oa + 1 + u)); pq[u][1] = ld(2 * (oa + 1 + u) + 1); }
+
+    const int k = plane % a.c;
+    const bool has_m = a.mults != nullptr;
+    const double mk = has_m ? a.mults[k] : 1.0;
+    int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+    double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
+    const int role = tid >> 7, wcol = tid & 127;
+    const int ow = ow0 + wcol;
+    const bool wr = wcol < SW && ow < a.out_w;
+    uint32_t amax = 0;
+    const int par = tid & 1, hc = tid >> 1;
+
+    for (int o0 = oa; o0 < ob; o0 += MW_PF) {
+#pragma unroll
+        for (int u = 0; u < MW_PF; u++) {
+            const int o = o0 + u;
+            // ---- axis -2 for output row o ----
+            double sl = 0.0, shh = 0.0;
+#pragma unroll
+            for (int j = 0; j < F; j++) {
+                if ((LOM >> j) & 1u) sl += a.lo[j] * win[F - 1 - j];
+                if ((HIM >> j) & 1u) shh += a.hi[j] * win[F - 1 - j];
+            }
+            s_lo[u & 1][par][hc] = sl;
+            s_hi[u & 1][par][hc] = shh;
+            // slide the window and refill the look-ahead slot
+#pragma unroll
+            for (int t = 0; t < F - 2; t++) win[t] = win[t + 2];
+            win[F - 2] = pq[u][0];
+            win[F - 1] = pq[u][1];
+            pq[u][0] = ld(2 * (o + 1 + MW_PF));
+            pq[u][1] = ld(2 * (o + 1 + MW_PF) + 1);
+            __syncthreads();
+            // ---- axis -1: two sub-bands per thread ----
+            if (wr && o < ob) {
+                const double(*src)[HC] = role ? s_hi[u & 1] : s_lo[u & 1];
+                double r0 = 0.0, r1 = 0.0;  // role 0: aa, ad   role 1: da, dd
+#pragma unroll
+                for (int j = 0; j < F; j++) {
+                    const double v = src[(F - 1 - j) & 1][wcol + ((F - 1 - j) >> 1)];
+                    if ((LOM >> j) & 1u) r0 += a.lo[j] * v;
+                    if ((HIM >> j) & 1u) r1 += a.hi[j] * v;
+                }
+                const int32_t q1 = quant(r1, mk, a.q, has_m);
+                amax = max(amax, iabs_u(q1));
+                if (role == 0) {
+                    if (a.last) {
+                        const int32_t q0 = quant(r0, mk, a.q, has_m);
+                        co[(size_t)o * a.enc_w + ow] = q0;
+                        amax = max(amax, iabs_u(q0));
+                    } else {
+                        llo[(size_t)o * a.out_w + ow] = r0;
+                    }
+                    co[(size_t)o * a.enc_w + a.off_w + ow] = q1;                      // 'ad' top-right
+                } else {
+                    const int32_t q0 = quant(r0, mk, a.q, has_m);
+                    amax = max(amax, iabs_u(q0));
+                    co[(size_t)(a.off_h + o) * a.enc_w + ow] = q0;                     // 'da' bottom-left
+                    co[(size_t)(a.off_h + o) * a.enc_w + a.off_w + ow] = q1;           // 'dd' bottom-right
+                }
+            }
+        }
     }
     if (a.maxabs != nullptr) {
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
@@ -327,6 +430,13 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
+    static const int use_march = [] { const char *e = getenv("SPIHT_DWT_MARCH"); return e ? atoi(e) : 0; }();
+    if (use_march) {
+        constexpr int SW = (256 - (F - 2)) / 2;
+        const uint32_t gx = (uint32_t)((a.out_w + SW - 1) / SW), gy = (uint32_t)((a.out_h + MW_ROWS - 1) / MW_ROWS);
+        hipLaunchKernelGGL((k_dwt_march<F, LOM, HIM>), dim3(gx * gy * (uint32_t)planes), dim3(256), 0, st, a, gx, gy);
+        return (int)hipGetLastError();
+    }
     uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
     hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
