@@ -53,7 +53,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU baseline codes (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: encode of step i+1 (stream A) overlaps decode of step i (stream B), double-buffered streams")
+                    help="1: encode of step i+1 (stream A) overlaps decode of step i (stream B), double-buffered streams. "
+                         "Measured: +6 %% (28.1 vs 29.7 ms/step): the decoder slows from 12.6 to 18 ms when the HBM is "
+                         "saturated by the other stream; restricting the streams to disjoint CU sets changed nothing")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
