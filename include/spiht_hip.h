@@ -87,6 +87,22 @@ int spiht_encode_bound(int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll
 int spiht_decode_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
                      int64_t w, int64_t ll_h, int64_t ll_w, int32_t *out);
 
+/* Replaces `decode_with_metadata(data_u8, n, c, h, w, ll_h, ll_w, top_slice, other_slices)
+ *           -> (ndarray[int32,(c,h,w)], ndarray[int32,(8*nbytes+1, 8)])`
+ * (src/lib.rs:47-56 -> encoder_decoder.rs:631-841, Slices::from_vec :482-527).
+ * top_slice: {start_i, end_i, start_j, end_j} of the LL block; other_slices: [level][3][4], coarsest level
+ * first, per level the three filters in the caller's order (the reference wrapper passes da, ad, dd,
+ * spiht_wrapper.py:240), each {start_i, end_i, start_j, end_j}.  level = other_slices.len().
+ * meta: (8*nbytes + 1) rows of 8 int32 {action 0..6, local_h, local_w, channel, filter 0..3, depth, n, value of
+ * the coefficient before the bit is read} (doc comment :616-630); row t describes the operation that reads
+ * stream bit t, row 8*nbytes the operation left waiting when the stream ended, rows of bits that were never
+ * reached are zero.
+ * Errors: SPIHT_ERR_SHAPE when the tree is deeper than `level` (the reference indexes other_slices out of
+ * bounds -> panic, :603), when a slice is empty or reversed (end <= start, usize underflow) or c*h*w >= 2^28. */
+int spiht_decode_with_metadata_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c,
+                                   int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, const int64_t *top_slice,
+                                   const int64_t *other_slices, int64_t level, int32_t *out, int32_t *meta);
+
 /* ---------------------------------------------------------------------------------------
  * Batched, device-resident forms (new; the reference codes one image per call).
  * All pointers below are DEVICE pointers (hipMalloc'd by anyone, e.g. a torch tensor's data_ptr()).

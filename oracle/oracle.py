@@ -51,6 +51,9 @@ def lib():
         L.orc_decode.restype = C.c_int
         L.orc_decode_bits.argtypes = L.orc_decode.argtypes
         L.orc_decode_bits.restype = C.c_int
+        L.orc_decode_with_metadata.argtypes = [C.c_void_p, u64, C.c_uint8, i64, i64, i64, i64, i64, C.c_void_p,
+                                               C.c_void_p, i64, C.c_void_p, C.c_void_p]
+        L.orc_decode_with_metadata.restype = C.c_int
         L.orc_free.argtypes = [C.c_void_p]
         L.orc_set_bit.argtypes = [C.c_int32, C.c_uint8, C.c_int]
         L.orc_set_bit.restype = C.c_int32
@@ -143,6 +146,29 @@ def decode_bits(bits, n, c, h, w, ll_h, ll_w, rule=RULE_RUST):
                                out.ctypes.data)
     _check(rc)
     return out
+
+
+def flatten_slices(top_slice, other_slices):
+    """lib.rs:49 argument structures -> (int64[4], int64[level*3*4], level) in Slices::from_vec order (:482-527)"""
+    top = np.array([top_slice[0][0], top_slice[0][1], top_slice[1][0], top_slice[1][1]], dtype=np.int64)
+    other = np.array([[[f[0][0], f[0][1], f[1][0], f[1][1]] for f in lv] for lv in other_slices],
+                     dtype=np.int64).reshape(-1)
+    return top, np.ascontiguousarray(other if other.size else np.zeros(1, np.int64)), len(other_slices)
+
+
+def decode_with_metadata(data, n, c, h, w, ll_h, ll_w, top_slice, other_slices):
+    """src/lib.rs:47-56 -> (rec int32[c,h,w], metadata int32[8*len(data)+1, 8]).  Metadata rows: parity unpinned."""
+    data = bytes(bytearray(data))
+    top, other, level = flatten_slices(top_slice, other_slices)
+    out = np.empty((c, h, w), dtype=np.int32)
+    meta = np.empty((8 * len(data) + 1, 8), dtype=np.int32)
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    rc = lib().orc_decode_with_metadata(buf, len(data), n, c, h, w, ll_h, ll_w, top.ctypes.data, other.ctypes.data,
+                                        level, out.ctypes.data, meta.ctypes.data)
+    if rc == 4:
+        raise OraclePanic("index out of bounds in get_local_position")
+    _check(rc)
+    return out, meta
 
 
 def bytes_to_bits(b):

@@ -422,6 +422,240 @@ cleanup:
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * decode_with_metadata (encoder_decoder.rs:631-841).  Parity of the metadata rows is UNPINNED: the
+ * reference holds no expected rows anywhere (its tests only compare the decoded array, :929-966,
+ * test_spiht.py:19-28) and the Rust core cannot be built here; this is a restatement of the source.
+ * ------------------------------------------------------------------------------------------------ */
+
+/* CoefficientMetadata, encoder_decoder.rs:123-151 (depth is a u8 and wraps in a release build) */
+typedef struct {
+    uint8_t t, depth, filter;
+    uint32_t k, i, j;
+} ment;
+typedef struct {
+    ment *e;
+    uint64_t head, tail, cap;
+} mfifo;
+
+static int mfifo_push(mfifo *f, ment m) {
+    if (f->tail == f->cap) {
+        if (f->head > f->cap / 2) {
+            memmove(f->e, f->e + f->head, (f->tail - f->head) * sizeof(ment));
+            f->tail -= f->head;
+            f->head = 0;
+        } else {
+            uint64_t nc = f->cap ? f->cap * 2 : 1024;
+            ment *ne = (ment *)realloc(f->e, nc * sizeof(ment));
+            if (!ne) return -1;
+            f->e = ne;
+            f->cap = nc;
+        }
+    }
+    f->e[f->tail++] = m;
+    return 0;
+}
+static inline uint64_t mfifo_len(const mfifo *f) { return f->tail - f->head; }
+
+/* encoder_decoder.rs:133-150 */
+static uint8_t offspring_filter(const ment *m) {
+    if (m->filter == 0) {
+        if (m->i % 2 == 1 && m->j % 2 == 1) return 3; /* DD */
+        if (m->i % 2 == 0 && m->j % 2 != 0) return 2; /* AD */
+        return 1;                                     /* DA */
+    }
+    return m->filter;
+}
+
+/* Rust `f32 as i32`: truncation toward zero, saturating, NaN -> 0 */
+static int32_t f32_as_i32(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return INT32_MAX;
+    if (v <= -2147483648.0f) return INT32_MIN;
+    return (int32_t)v;
+}
+
+#define ORC_ERR_SLICE 4 /* index out of bounds in get_local_position (:603) -> Rust panic */
+
+/* encoder_decoder.rs:593-613.  top = {start_i,end_i,start_j,end_j}; other = [level][3][4] same order.
+ * volatile keeps gcc from contracting or reassociating the f32 steps. */
+static int local_position(const ment *m, const int64_t *top, const int64_t *other, int64_t level, int32_t *lh,
+                          int32_t *lw) {
+    volatile float local_h, local_w;
+    if (m->depth == (uint8_t)level) {
+        local_h = (float)m->i / (float)top[1];
+        local_w = (float)m->j / (float)top[3];
+    } else {
+        uint8_t depth_i = (uint8_t)((uint8_t)level - 1 - m->depth);
+        uint64_t filter_i = (uint64_t)m->filter - 1;
+        if (depth_i >= level || filter_i >= 3) return ORC_ERR_SLICE;
+        const int64_t *s = other + ((int64_t)depth_i * 3 + (int64_t)filter_i) * 4;
+        volatile float a = (float)m->i - (float)s[0];
+        volatile float b = (float)(uint64_t)(s[1] - s[0]);
+        local_h = a / b;
+        a = (float)m->j - (float)s[2];
+        b = (float)(uint64_t)(s[3] - s[2]);
+        local_w = a / b;
+    }
+    volatile float th = local_h * 200000.0f, tw = local_w * 200000.0f;
+    volatile float uh = th - 100000.0f, uw = tw - 100000.0f;
+    *lh = f32_as_i32(uh);
+    *lw = f32_as_i32(uw);
+    return ORC_OK;
+}
+
+/* encoder_decoder.rs:631-841.  `bits` one bit per byte; out: c*h*w (zeroed here); meta: (nbits+1)*8 (zeroed here). */
+int orc_decode_with_metadata_bits(const uint8_t *bits, uint64_t nbits, uint8_t n, int64_t c, int64_t h, int64_t w,
+                                  int64_t ll_h, int64_t ll_w, const int64_t *top, const int64_t *other, int64_t level,
+                                  int32_t *out, int32_t *meta) {
+    memset(out, 0, (size_t)(c * h * w) * sizeof(int32_t));
+    memset(meta, 0, (size_t)(nbits + 1) * 8 * sizeof(int32_t));
+    if (!(ll_h > 1) || !(ll_w > 1)) return ORC_ERR_LL;
+    int rc = ORC_OK;
+    uint64_t cur = 0;
+#define REC(k, i, j) out[((int64_t)(k) * h + (int64_t)(i)) * w + (int64_t)(j)]
+#define POP_BIT(dst)                 \
+    do {                             \
+        if (cur >= nbits) goto done; \
+        (dst) = bits[cur++];         \
+    } while (0)
+/* :664-684; `metadata_arr.len()` (:668) is the element count, so that guard never trips before pop_bit's */
+#define ASSIGN(action, m)                                               \
+    do {                                                                \
+        int32_t lh_, lw_;                                               \
+        rc = local_position(&(m), top, other, level, &lh_, &lw_);       \
+        if (rc) goto cleanup;                                           \
+        int32_t *row = meta + cur * 8;                                  \
+        row[0] = (action); row[1] = lh_; row[2] = lw_;                  \
+        row[3] = (int32_t)(m).k; row[4] = (m).filter; row[5] = (m).depth; \
+        row[6] = n; row[7] = REC((m).k, (m).i, (m).j);                  \
+    } while (0)
+
+    mfifo lsp = {0}, lip = {0}, lis = {0}, lip_retain = {0}, lis_retain = {0};
+    for (int64_t i = 0; i < ll_h; i++)
+        for (int64_t j = 0; j < ll_w; j++)
+            for (int64_t k = 0; k < c; k++) {
+                ment m = {0, (uint8_t)level, 0, (uint32_t)k, (uint32_t)i, (uint32_t)j};
+                if (mfifo_push(&lip, m)) goto nomem;
+            }
+    for (int64_t i = 0; i < ll_h; i++)
+        for (int64_t j = 0; j < ll_w; j++) {
+            if (i % 2 == 0 && j % 2 == 0) continue;
+            for (int64_t k = 0; k < c; k++) {
+                ment m = {1, (uint8_t)level, 0, (uint32_t)k, (uint32_t)i, (uint32_t)j};
+                if (mfifo_push(&lis, m)) goto nomem;
+            }
+        }
+
+    for (;;) {
+        uint64_t lsp_len = mfifo_len(&lsp);
+        int32_t base_sig = (n == 0) ? 1 : (int32_t)((1u << (n - 1)) + (1u << n));
+
+        lip_retain.head = lip_retain.tail = 0;
+        while (mfifo_len(&lip)) {
+            ment e = lip.e[lip.head++];
+            int is_sig, sb;
+            ASSIGN(0, e);
+            POP_BIT(is_sig);
+            if (is_sig) {
+                ASSIGN(1, e);
+                POP_BIT(sb);
+                REC(e.k, e.i, e.j) = base_sig * (sb * 2 - 1);
+                if (mfifo_push(&lsp, e)) goto nomem;
+            } else {
+                if (mfifo_push(&lip_retain, e)) goto nomem;
+            }
+        }
+        { mfifo t = lip; lip = lip_retain; lip_retain = t; }
+
+        lis_retain.head = lis_retain.tail = 0;
+        while (mfifo_len(&lis)) {
+            ment e = lis.e[lis.head++];
+            int64_t o[4][2];
+            if (e.t) {
+                int desc_sig;
+                ASSIGN(2, e);
+                POP_BIT(desc_sig);
+                if (desc_sig) {
+                    if (orc_get_offspring(e.i, e.j, h, w, ll_h, ll_w, o)) {
+                        for (int q = 0; q < 4; q++) {
+                            ment nc = {0, (uint8_t)(e.depth - 1), offspring_filter(&e), e.k, (uint32_t)o[q][0],
+                                       (uint32_t)o[q][1]};
+                            int sig, sb;
+                            ASSIGN(3, nc);
+                            POP_BIT(sig);
+                            if (sig) {
+                                ASSIGN(4, nc);
+                                POP_BIT(sb);
+                                REC(nc.k, nc.i, nc.j) = (sb * 2 - 1) * base_sig;
+                                if (mfifo_push(&lsp, nc)) goto nomem;
+                            } else {
+                                if (mfifo_push(&lip, nc)) goto nomem;
+                            }
+                        }
+                    }
+                    if (has_descendents_past_offspring(e.i, e.j, h, w, 0)) {
+                        ment b = e;
+                        b.t = 0;
+                        if (mfifo_push(&lis, b)) goto nomem;
+                    }
+                } else {
+                    if (mfifo_push(&lis_retain, e)) goto nomem;
+                }
+            } else {
+                int l_sig;
+                ASSIGN(5, e);
+                POP_BIT(l_sig);
+                if (l_sig) {
+                    if (orc_get_offspring(e.i, e.j, h, w, ll_h, ll_w, o))
+                        for (int q = 0; q < 4; q++) {
+                            ment nc = {1, (uint8_t)(e.depth - 1), offspring_filter(&e), e.k, (uint32_t)o[q][0],
+                                       (uint32_t)o[q][1]};
+                            if (mfifo_push(&lis, nc)) goto nomem;
+                        }
+                } else {
+                    if (mfifo_push(&lis_retain, e)) goto nomem;
+                }
+            }
+        }
+        { mfifo t = lis; lis = lis_retain; lis_retain = t; }
+
+        for (uint64_t q = 0; q < lsp_len; q++) {
+            ment e = lsp.e[lsp.head + q];
+            int b;
+            ASSIGN(6, e);
+            POP_BIT(b);
+            REC(e.k, e.i, e.j) = orc_set_bit(REC(e.k, e.i, e.j), n, b);
+        }
+
+        if (n == 0) break;
+        n -= 1;
+    }
+#undef POP_BIT
+#undef ASSIGN
+#undef REC
+done:
+    goto cleanup;
+nomem:
+    rc = ORC_ERR_NOMEM;
+cleanup:
+    free(lsp.e); free(lip.e); free(lis.e); free(lip_retain.e); free(lis_retain.e);
+    return rc;
+}
+
+/* lib.rs:47-56 with bytes_to_bits lib.rs:15-21 */
+int orc_decode_with_metadata(const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h, int64_t w,
+                             int64_t ll_h, int64_t ll_w, const int64_t *top, const int64_t *other, int64_t level,
+                             int32_t *out, int32_t *meta) {
+    uint64_t nbits = nbytes * 8;
+    uint8_t *bits = (uint8_t *)malloc(nbits ? nbits : 1);
+    if (!bits) return ORC_ERR_NOMEM;
+    for (uint64_t t = 0; t < nbits; t++) bits[t] = (data[t >> 3] >> (t & 7)) & 1;
+    int rc = orc_decode_with_metadata_bits(bits, nbits, n, c, h, w, ll_h, ll_w, top, other, level, out, meta);
+    free(bits);
+    return rc;
+}
+
 void orc_free(void *p) { free(p); }
 
 /* lib.rs:24-32: encode + `data.chunks(8).map(load_le::<u8>)` (bit t -> bit t%8 of byte t/8).

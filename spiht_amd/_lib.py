@@ -35,7 +35,7 @@ SYMBOLS = [
     "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
     "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
     "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
-    "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
+    "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
     "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset",
@@ -75,6 +75,7 @@ def lib():
                                        C.POINTER(u8)]
         L.spiht_encode_bound.argtypes = [i64, i64, i64, i64, i64, C.c_uint32, u64, C.POINTER(u64)]
         L.spiht_decode_i32.argtypes = [vp, vp, u64, u8, i64, i64, i64, i64, i64, vp]
+        L.spiht_decode_with_metadata_i32.argtypes = [vp, vp, u64, u8, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp]
         L.spiht_encode_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, u64, vp, u64, vp, vp]
         L.spiht_decode_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
         L.spiht_wavelet_id.argtypes = [C.c_char_p]

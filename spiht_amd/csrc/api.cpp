@@ -20,6 +20,9 @@ int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxab
 int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
+int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes);
+int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                          void *temp, size_t temp_bytes, hipStream_t st);
 int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
@@ -75,6 +78,7 @@ struct spiht_ctx {
     float log2_thresh[32];
     // grow-only scratch
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
+    DevBuf trace, meta;  // decode_with_metadata
     // timing
     bool timing = false;
     struct Rec { int stage; hipEvent_t a, b; };
@@ -344,7 +348,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
-                      &ctx->img};
+                      &ctx->img, &ctx->trace, &ctx->meta};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -512,7 +516,8 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
 }
 
 static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, uint64_t slot_stride,
-                         const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out) {
+                         const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out,
+                         uint32_t *d_tr_ent = nullptr, uint8_t *d_tr_act = nullptr, uint64_t tr_stride = 0) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if (slot_stride * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
     ListCaps caps;
@@ -538,6 +543,7 @@ static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, u
     a.lip0 = lp.lip0; a.lip1 = lp.lip1; a.lsp_idx = lp.lsp; a.lsp_val = lp.lsp_val;
     a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
     a.err = (uint32_t *)ctx->err.p;
+    a.tr_ent = d_tr_ent; a.tr_act = d_tr_act; a.tr_stride = tr_stride;
     {
         StageTimer t(ctx, ST_DEC_LISTS);
         LAUNCHCHK(spiht_launch_decode(&a, ctx->stream));
@@ -651,6 +657,93 @@ extern "C" int spiht_decode_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nb
     {
         StageTimer t(ctx, ST_D2H);
         HIPCHK(hipMemcpyAsync(out, ctx->rec.p, (size_t)g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+// number of generations below the LL block that exist in the index-based tree (encoder_decoder.rs:43-75): the
+// shallowest first-generation nodes are (0, ll_w) and (ll_h, 0); a node has offspring iff 2i+1 < h && 2j+1 < w
+static int tree_generations(const Geom &g) {
+    int best = 1;
+    const int64_t cand[2][2] = {{0, g.ll_w}, {g.ll_h, 0}};
+    for (auto &cd : cand) {
+        int t = 1;
+        while (t < 40 && 2 * (cd[0] << (t - 1)) + 1 < g.h && 2 * (cd[1] << (t - 1)) + 1 < g.w) t++;
+        best = std::max(best, t);
+    }
+    return best;
+}
+
+extern "C" int spiht_decode_with_metadata_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c,
+                                              int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, const int64_t *top_slice,
+                                              const int64_t *other_slices, int64_t level, int32_t *out, int32_t *meta) {
+    if (!ctx || !out || !meta || (!data && nbytes) || !top_slice || level < 0 || (level > 0 && !other_slices))
+        return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (g.n >= (1u << 28)) return SPIHT_ERR_TOO_LARGE;  // list entries carry the filter in bits 28-29
+    if (n > 30) return SPIHT_ERR_MAGNITUDE;
+    if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
+    if (level > 255 || tree_generations(g) > level) return SPIHT_ERR_SHAPE;  // other_slices[depth_i] out of bounds (:603)
+    std::vector<int32_t> sl(4 + (size_t)level * 12);
+    for (size_t t = 0; t < sl.size(); t++) {
+        const int64_t v = t < 4 ? top_slice[t] : other_slices[t - 4];
+        if (v < 0 || v > 0x7FFFFFFF) return SPIHT_ERR_ARG;
+        sl[t] = (int32_t)v;
+    }
+    for (size_t t = 4; t < sl.size(); t += 4)
+        if (sl[t + 1] < sl[t] || sl[t + 3] < sl[t + 2]) return SPIHT_ERR_SHAPE;  // usize underflow in end - start (:606-608)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
+    const uint64_t rows = nbytes * 8 + 1;
+    size_t sort_bytes = 0;
+    if (spiht_meta_sort_temp_bytes(rows, &sort_bytes) != 0) return SPIHT_ERR_INTERNAL;
+    // trace scratch: ent[rows] u32 | 4 x u32[rows] sort buffers | act[rows] u8 | slices | sort temp
+    const size_t o_ent = 0, o_k0 = align256(rows * 4), o_v0 = o_k0 + align256(rows * 4), o_k1 = o_v0 + align256(rows * 4),
+                 o_v1 = o_k1 + align256(rows * 4), o_act = o_v1 + align256(rows * 4), o_sl = o_act + align256(rows),
+                 o_tmp = o_sl + align256(sl.size() * 4), total = o_tmp + align256(sort_bytes);
+    CHK(ensure(ctx, ctx->data, slot));
+    CHK(ensure(ctx, ctx->nbytes, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(ensure(ctx, ctx->rec, (size_t)g.n * 4));
+    CHK(ensure(ctx, ctx->trace, total));
+    CHK(ensure(ctx, ctx->meta, rows * 32));
+    char *tb = (char *)ctx->trace.p;
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemsetAsync(ctx->data.p, 0, slot, ctx->stream));
+        if (nbytes) HIPCHK(hipMemcpyAsync(ctx->data.p, data, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->nbytes.p, &nbytes, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->maxn.p, &n, 1, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(tb + o_sl, sl.data(), sl.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(tb + o_act, TR_NONE, rows, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // stack / vector temporaries
+    }
+    CHK(decode_device(ctx, g, (const uint8_t *)ctx->data.p, slot, (const uint64_t *)ctx->nbytes.p,
+                      (const uint8_t *)ctx->maxn.p, 1, (int32_t *)ctx->rec.p, (uint32_t *)(tb + o_ent),
+                      (uint8_t *)(tb + o_act), rows));
+    MetaArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    ma.g = g;
+    ma.level = (int32_t)level;
+    ma.rows = rows;
+    ma.tr_ent = (const uint32_t *)(tb + o_ent);
+    ma.tr_act = (const uint8_t *)(tb + o_act);
+    ma.data = (const uint8_t *)ctx->data.p;
+    ma.slices = (const int32_t *)(tb + o_sl);
+    ma.meta = (int32_t *)ctx->meta.p;
+    ma.skey = (const uint32_t *)(tb + o_k1);
+    ma.spos = (const uint32_t *)(tb + o_v1);
+    LAUNCHCHK(spiht_launch_metadata(&ma, (uint32_t *)(tb + o_k0), (uint32_t *)(tb + o_v0), (uint32_t *)(tb + o_k1),
+                                    (uint32_t *)(tb + o_v1), tb + o_tmp, sort_bytes, ctx->stream));
+    CHK(read_err(ctx));
+    {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(out, ctx->rec.p, (size_t)g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(meta, ctx->meta.p, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPIHT_OK;

@@ -87,6 +87,33 @@ struct DecArgs {
     uint32_t *lip0, *lip1, *lsp_idx, *lis0, *lis1, *lis2;
     int32_t *lsp_val;
     uint32_t *err;
+    // decode_with_metadata only (k_decode<true>): one trace record per stream position 0..nbits (the last one is
+    // the operation that was waiting for a bit when the stream ended)
+    uint32_t *tr_ent;         // [B, tr_stride]  entry: node index | filter << 28 (| ENT_A / ENT_LEAF, ignored)
+    uint8_t *tr_act;          // [B, tr_stride]  action 0..6 | plane << 3;  TR_NONE where no operation starts
+    uint64_t tr_stride;       // records per image (>= 8*nbytes + 1)
+};
+
+// decode_with_metadata: list entries also carry the filter (encoder_decoder.rs:457-462) in bits 28-29, because
+// on trees with duplicated nodes (odd ll_h / ll_w) the same node is reached under two different filters; the
+// index is then limited to 28 bits.
+#define ENT_IDX_META 0x0FFFFFFFu
+#define ENT_FILT_SHIFT 28
+#define TR_NONE 0xFFu
+
+// k_meta_rows / k_meta_fold (metadata.hip)
+struct MetaArgs {
+    Geom g;
+    int32_t level;            // number of detail levels (Slices.other_slices.len())
+    int32_t pad;
+    uint64_t rows;            // 8*nbytes + 1
+    const uint32_t *tr_ent;   // [rows]
+    const uint8_t *tr_act;    // [rows]
+    const uint8_t *data;      // stream bytes
+    const int32_t *slices;    // device: top {start_i,end_i,start_j,end_j}, then [level][3][4]
+    int32_t *meta;            // [rows, 8]
+    const uint32_t *skey;     // sorted node index per record (fold)
+    const uint32_t *spos;     // record position, sorted by (node index, position)
 };
 
 struct PyrArgs {

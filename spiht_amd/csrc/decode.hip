@@ -197,6 +197,7 @@ struct LipWin {
     uint64_t sig;      // those of them that are significant ('1 s')
     uint32_t ntok;     // tokens of the pass that start in this window (including a truncated last one)
     uint32_t trunc;    // the last token has its sign bit past the end of the stream: decoding stops
+    uint32_t trunc_pos;  // ... and starts at this window bit
     uint32_t ends;     // the pass ends inside this window
     uint32_t pos1;     // ... at this bit
     uint32_t cout;
@@ -220,9 +221,10 @@ __device__ __forceinline__ LipWin lip_window(uint64_t lo, uint32_t Wb, uint32_t 
     uint64_t sg = S & lo;
     // a '1' whose sign bit is at or past nbits (only the very last token of the stream can be)
     r.trunc = 0;
+    r.trunc_pos = 0;
     if (sg) {
         const uint32_t top = 63u - (uint32_t)__builtin_clzll(sg);
-        if (Wb + top + 1 >= nbits) { r.trunc = 1; sg &= ~(1ull << top); S &= ~(1ull << top); }
+        if (Wb + top + 1 >= nbits) { r.trunc = 1; r.trunc_pos = top; sg &= ~(1ull << top); S &= ~(1ull << top); }
     }
     r.S_in = S;
     r.sig = sg;
@@ -344,15 +346,42 @@ __device__ __forceinline__ void tail_push(DecShared &sh, uint32_t key, uint32_t 
     if (tp < DEC_TAIL) { sh.tail[tp].key = key; sh.tail[tp].idx = idx; sh.tail[tp].val = val; sh.tail[tp].n = n; }
 }
 
+// ---- decode_with_metadata trace (k_decode<true> only): which list entry every stream position belongs to ----
+struct Trace {
+    uint32_t *ent;
+    uint8_t *act;
+    uint32_t nbits;
+};
+// record for stream position `pos`; position nbits is the operation left waiting when the stream ended
+// (encoder_decoder.rs:664-684 assigns the row BEFORE pop_bit returns, :649-651)
+__device__ __forceinline__ void tr_put(const Trace &tr, uint32_t pos, uint32_t act, int n, uint32_t e) {
+    if (pos <= tr.nbits) {
+        tr.ent[pos] = e;
+        tr.act[pos] = (uint8_t)(act | ((uint32_t)n << 3));
+    }
+}
+
 // ---- per-lane work of one LIP window (worker) ----
+template <bool META>
 __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const Item &it, const uint32_t *lip,
                                          uint32_t *lipn, uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits,
-                                         uint32_t tail_start, int n, int32_t base_val, uint32_t lane) {
+                                         uint32_t tail_start, int n, int32_t base_val, uint32_t lane, const Trace &tr) {
     const LipWin lw = lip_window(it.lo, it.Wb, it.pos0, it.cin, it.m_rem, nbits);
     const bool isS = (lw.S_in >> lane) & 1ull;
     const uint32_t rank = mbcnt(lw.S_in);
     const bool sig = (lw.sig >> lane) & 1ull;
     const uint32_t e = isS ? lip[it.e_start + rank] : 0u;
+    if (META) {
+        if (isS) {
+            tr_put(tr, it.Wb + lane, 0, n, e);              // action 0 (:707)
+            if (sig) tr_put(tr, it.Wb + lane + 1, 1, n, e);  // action 1 (:712)
+        }
+        if (lw.trunc && lane == 0) {  // '1' in the last bit of the stream: its sign row is the waiting one
+            const uint32_t et = lip[it.e_start + (uint32_t)__popcll(lw.S_in)];
+            tr_put(tr, it.Wb + lw.trunc_pos, 0, n, et);
+            tr_put(tr, nbits, 1, n, et);
+        }
+    }
     if (isS && sig) {
         const uint32_t sgn = lane < 63 ? ((uint32_t)(it.lo >> (lane + 1)) & 1u) : ((uint32_t)it.hi & 1u);
         const uint32_t t = it.b_lsp + mbcnt(lw.sig);
@@ -369,11 +398,13 @@ __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const 
 }
 
 // ---- per-lane work of one LIS window (worker); lane = stream position inside the window ----
+template <bool META>
 __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const Geom &g, const Item &it, uint32_t seqno,
                                          const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
                                          uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
-                                         int32_t base_val, uint32_t lane) {
+                                         int32_t base_val, uint32_t lane, const Trace &tr) {
     const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
+    constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
     // entry starts: owned bits that are not child bits of a fired type-A entry starting in this window
     const uint64_t own = (it.pos1 >= 64 ? ~0ull : ((1ull << it.pos1) - 1ull)) & (~0ull << it.pos0);
     const uint64_t below = it.fm & ((1ull << lane) - 1ull);
@@ -394,12 +425,14 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
     const uint64_t ES = __ballot(isE);
     const uint32_t mypos = it.Wb + lane;
     const uint32_t e = isE ? cur[it.e_start + mbcnt(ES)] : 0u;
-    const uint32_t idx = e & ENT_IDX;
+    const uint32_t idx = e & IDXM;
     const bool isA = (e & ENT_A) != 0;
     const bool leaf = (e & ENT_LEAF) != 0;
     uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
     uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
+    uint32_t cf = 0;  // META: filter of the offspring, in entry position (get_offspring_filter, :133-150)
     bool fired = false;
+    if (META && isE) tr_put(tr, mypos, isA ? 2u : 5u, n, e);  // action 2 (:735) / action 5 (:787)
     if (isE) {
         const uint32_t avail = nbits - mypos;  // >= 1: the sequencer never places an entry at or past nbits
         const uint64_t bb = lane ? ((it.lo >> lane) | (it.hi << (64 - lane))) : it.lo;
@@ -415,6 +448,11 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
             uint32_t k, ii, jj;
             decomp(g, idx, k, ii, jj);
             cb = child_base(g, k, ii, jj, cr, ccol);
+            if (META) {
+                const uint32_t pf = (e >> ENT_FILT_SHIFT) & 3u;
+                const uint32_t fl = pf ? pf : (((ii & 1u) && (jj & 1u)) ? 3u : ((!(ii & 1u) && (jj & 1u)) ? 2u : 1u));
+                cf = fl << ENT_FILT_SHIFT;
+            }
             if (!isA) {
                 nQ = 4;
             } else {
@@ -423,6 +461,11 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (!stop) {
+                        if (META) {
+                            const uint32_t ch = (cb + (q >> 1) * W + (q & 1)) | cf;
+                            tr_put(tr, mypos + o, 3, n, ch);                                            // action 3 (:745)
+                            if (o < avail && ((bits >> o) & 1u)) tr_put(tr, mypos + o + 1, 4, n, ch);  // action 4 (:749)
+                        }
                         if (o >= avail) { stop = true; }
                         else if ((bits >> o) & 1u) {
                             if (o + 1 >= avail) { stop = true; }
@@ -483,17 +526,17 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
             // fired leaf: dropped
         } else if (!isA) {
             const uint32_t oq = b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4);
-            nxt[oq] = make_a_entry(cb, cr, ccol, H, W);
-            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W);
-            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W);
-            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W);
+            nxt[oq] = make_a_entry(cb, cr, ccol, H, W) | cf;
+            nxt[oq + 1] = make_a_entry(cb + 1, cr, ccol + 1, H, W) | cf;
+            nxt[oq + 2] = make_a_entry(cb + W, cr + 1, ccol, H, W) | cf;
+            nxt[oq + 3] = make_a_entry(cb + W + 1, cr + 1, ccol + 1, H, W) | cf;
         } else {
             uint32_t ol = b_lip + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
             uint32_t os = b_lsp + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
             uint32_t o = 1;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const uint32_t ci = cb + (q >> 1) * W + (q & 1);
+                const uint32_t ci = (cb + (q >> 1) * W + (q & 1)) | cf;
                 if (sigm & (1u << q)) {
                     const int32_t v = ((signm >> q) & 1u) ? base_val : -base_val;
                     const bool tl = (tailm >> q) & 1u;
@@ -507,17 +550,18 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
                     o += 1;
                 }
             }
-            if (nQ) nxt[b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = idx;  // type B
+            if (nQ) nxt[b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = e & ~(ENT_A | ENT_LEAF);  // type B
         }
     }
 }
 
 // worker loop of one phase: consume items until the sequencer closes the phase
+template <bool META>
 __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, const Geom &g, uint32_t &myk, uint32_t par,
                                              const uint32_t *lip_rd, uint32_t *lip_wr, uint32_t *lip_app,
                                              const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lsp_idx,
                                              int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
-                                             int32_t base_val, uint32_t wk, uint32_t lane) {
+                                             int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr) {
     for (;;) {
         bool got = false;
         uint32_t spins = 0;
@@ -532,9 +576,10 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
         if (!got) break;
         const Item it = slot_unpack(sh.ring[myk % DEC_RING]);
         if (it.kind == 0)
-            work_lip(sh, a, it, lip_rd, lip_wr, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
+            work_lip<META>(sh, a, it, lip_rd, lip_wr, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
         else
-            work_lis(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
+            work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane,
+                           tr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
         myk += DEC_NWK;
@@ -553,8 +598,10 @@ __device__ __forceinline__ void seq_close(DecShared &sh, uint32_t par, uint32_t 
     if (lane == 0) lds_store(&sh.phase_end[par], seq);
 }
 
+template <bool META>
 __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
     __shared__ DecShared sh;
+    constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
     const Geom g = a.g;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -581,6 +628,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         bs.nbits = (uint32_t)(nby * 8);
         const uint32_t nbits = bs.nbits;
         const uint32_t tail_start = nbits >= 8 ? nbits - 8 : 0;
+        Trace tr;
+        tr.ent = META ? a.tr_ent + (size_t)b * a.tr_stride : nullptr;
+        tr.act = META ? a.tr_act + (size_t)b * a.tr_stride : nullptr;
+        tr.nbits = nbits;
         int n = (int)a.max_n[b];
         if (n > 30) { bad = true; n = 0; }
 
@@ -654,7 +705,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 uint32_t m_rem = lip_len, tok_base = 0, lipn_len = 0, cin = 0, lsp_l = lsp_len;
                 bool dn = false;
                 while (m_rem > 0 && !dn) {
-                    if (P >= nbits) { dn = true; break; }
+                    if (P >= nbits) {
+                        if (META && threadIdx.x == 0) tr_put(tr, nbits, 0, n, lip[tok_base]);  // waiting for a LIP bit
+                        dn = true;
+                        break;
+                    }
                     const uint32_t widx0 = P >> 6, gw = wave * 64 + lane;
                     const uint32_t widx = widx0 + gw, Wb = widx << 6;
                     const uint32_t pos = gw == 0 ? (P & 63u) : 0u;
@@ -691,7 +746,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     const uint32_t m_here = m_rem > before ? m_rem - before : 0u;
                     const bool in_pass = m_here > 0 && vb > 0;
                     LipWin lw;
-                    lw.S_in = 0; lw.sig = 0; lw.ntok = 0; lw.trunc = 0; lw.ends = 0; lw.pos1 = 64; lw.cout = 0;
+                    lw.S_in = 0; lw.sig = 0; lw.ntok = 0; lw.trunc = 0; lw.trunc_pos = 0; lw.ends = 0; lw.pos1 = 64; lw.cout = 0;
                     if (in_pass) lw = lip_window(lo, Wb, pos, my_cin, m_here, nbits);
                     const uint32_t nsig = (uint32_t)__popcll(lw.sig);
                     const uint32_t nnon = (uint32_t)__popcll(lw.S_in & ~lw.sig);
@@ -731,7 +786,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             it.kind = 0; it.Wb = q.Wb; it.pos0 = q.flags & 0xFFu; it.pos1 = 64; it.e_start = q.e_start;
                             it.cin = (q.flags >> 8) & 1u; it.m_rem = q.m_rem; it.first = 1; it.b_lsp = q.b_lsp; it.b_lip = q.b_lip;
                             it.b_nxt = 0; it.b_ret = 0; it.lo = q.lo; it.hi = (q.flags >> 9) & 1u; it.fm = 0;
-                            work_lip(sh, a, it, lip, lipn, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane);
+                            work_lip<META>(sh, a, it, lip, lipn, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
                         }
                     }
                     // ---- advance (every wave computes the same) ----
@@ -774,7 +829,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     uint32_t ent_nx = (64 + lane) < cur_len ? cur[64 + lane] : 0u;
                     uint64_t TA = __ballot((ent & ENT_A) && !(ent & ENT_LEAF));
                     while (i < cur_len) {
-                        if (P >= nbits) { dn = 1; break; }
+                        if (P >= nbits) {
+                            if (META && lane == 0) tr_put(tr, nbits, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
+                            dn = 1;
+                            break;
+                        }
                         const uint32_t widx = P >> 6, Wb = widx << 6, pos0 = P & 63u;
                         uint32_t pos = pos0;
                         uint64_t lo, hi;
@@ -896,8 +955,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     if (i < cur_len) dn = 1;  // stream exhausted before the queue
                     seq_close(sh, par, seq, P, dn, 0, 0, lane);
                 } else {
-                    worker_phase(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits, tail_start,
-                                 n, base_val, wave - 1, lane);
+                    worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,
+                                       tail_start, n, base_val, wave - 1, lane, tr);
                 }
                 PF_ADD(2);
                 __syncthreads();
@@ -943,8 +1002,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         const bool tl = in && (P + t >= tail_start);
                         if (in && !tl) lsp_val[t] = set_bit_i32(v[u], (uint32_t)n, bit[u]);
                         if (tl) tail_push(sh, P + t, lsp_idx[t], (int32_t)bit[u], (uint32_t)n | 0x80000000u);
+                        if (META && in) tr_put(tr, P + t, 6, n, lsp_idx[t]);  // action 6 (:822)
                     }
                 }
+                if (META && count < lsp_len0 && threadIdx.x == 0) tr_put(tr, nbits, 6, n, lsp_idx[count]);  // waiting
                 P += count;
                 if (count < lsp_len0) { cut = count; done = true; }
                 __syncthreads();
@@ -957,12 +1018,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         __syncthreads();
         for (uint32_t t = cut + threadIdx.x; t < lsp_len; t += DEC_NW * 64) {
             int32_t v = lsp_val[t];
-            if (v) out[lsp_idx[t]] = v;
+            if (v) out[lsp_idx[t] & IDXM] = v;
         }
         __syncthreads();
         for (uint32_t t = threadIdx.x; t < cut; t += DEC_NW * 64) {
             int32_t v = lsp_val[t];
-            if (v) out[lsp_idx[t]] = v;
+            if (v) out[lsp_idx[t] & IDXM] = v;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -973,6 +1034,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 for (uint32_t r = 0; r < nt; r++)
                     if (sh.tail[r].key < best) { best = sh.tail[r].key; bi = r; }
                 TailOp op = sh.tail[bi];
+                op.idx &= IDXM;
                 sh.tail[bi].key = 0xFFFFFFFFu;
                 if (op.n & 0x80000000u) out[op.idx] = set_bit_i32(out[op.idx], op.n & 0xFFu, (uint32_t)op.val);
                 else out[op.idx] = op.val;
@@ -995,6 +1057,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 extern "C" int spiht_launch_decode(const DecArgs *a, hipStream_t st) {
     int grid = a->nslots < a->B ? a->nslots : a->B;
     if (grid < 1) return 0;
-    hipLaunchKernelGGL(k_decode, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
+    if (a->tr_ent)
+        hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
+    else
+        hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
     return (int)hipGetLastError();
 }

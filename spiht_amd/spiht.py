@@ -101,6 +101,59 @@ def decode(data_u8, n, c, h, w, ll_h, ll_w):
     return out
 
 
-def decode_with_metadata(*args, **kwargs):
-    raise NotImplementedError(
-        "decode_with_metadata (src/lib.rs:47-56) is outside the accelerated hot path of this build (SURVEY.md 8 f-1)")
+def _as_pairs(v, name, count):
+    # PyO3 `Vec<(usize, usize)>`
+    if isinstance(v, str):
+        raise TypeError("argument '%s': Can't extract `str` to `Vec`" % name)
+    out = []
+    for p in list(v):
+        p = tuple(p)
+        if len(p) != 2:
+            raise ValueError("argument '%s': expected tuple of length 2, but got tuple of length %d" % (name, len(p)))
+        out.append((_as_usize(p[0], name), _as_usize(p[1], name)))
+    if count is not None and len(out) < count:
+        raise PanicException("index out of bounds: the len is %d but the index is %d" % (len(out), len(out)))
+    return out
+
+
+def decode_with_metadata(data_u8, n, c, h, w, ll_h, ll_w, top_slice, other_slices):
+    """Decode DWT coefficients from bytes and also return the intermediate metadata of the SPIHT algorithm
+    (src/lib.rs:47-56 -> encoder_decoder.rs:631-841).
+
+    top_slice: [(start_i, end_i), (start_j, end_j)] of the LL block; other_slices: per detail level, coarsest
+    first, three filters (the reference wrapper passes da, ad, dd), each [(start_i, end_i), (start_j, end_j)].
+    Returns (rec int32 (c,h,w), metadata int32 (8*len(data)+1, 8)); metadata row t, for the operation that
+    reads stream bit t: [action 0..6, local_h, local_w, channel, filter, depth, n, current coefficient value]
+    (doc comment encoder_decoder.rs:616-630)."""
+    buf = _as_u8_vec(data_u8)
+    n = _as_usize(n, "n")
+    if n > 255:
+        raise OverflowError("out of range integral type conversion attempted")
+    c, h, w = _as_usize(c, "c"), _as_usize(h, "h"), _as_usize(w, "w")
+    ll_h, ll_w = _as_usize(ll_h, "ll_h"), _as_usize(ll_w, "ll_w")
+    top = _as_pairs(top_slice, "top_slice", 2)                      # Slices::from_vec indexes [0] and [1] (:518-523)
+    levels = []
+    for lv in list(other_slices):
+        fl = [_as_pairs(f, "other_slices", 2) for f in list(lv)]
+        if len(fl) < 3:
+            raise PanicException("index out of bounds: the len is %d but the index is %d" % (len(fl), len(fl)))
+        levels.append(fl)
+    if ll_h <= 1 or ll_w <= 1:
+        raise PanicException("assertion failed: ll_h > 1")
+    rows = 8 * buf.size + 1
+    if c == 0:
+        return np.zeros((c, h, w), dtype=np.int32), np.zeros((rows, 8), dtype=np.int32)
+    if h == 0 or w == 0:
+        raise PanicException("ndarray: index out of bounds")  # the first metadata row reads rec_arr[(0,0,0)] (:683)
+    topv = np.array([top[0][0], top[0][1], top[1][0], top[1][1]], dtype=np.int64)
+    oth = np.array([[[f[0][0], f[0][1], f[1][0], f[1][1]] for f in lv[:3]] for lv in levels], dtype=np.int64).reshape(-1)
+    oth = np.ascontiguousarray(oth if oth.size else np.zeros(1, dtype=np.int64))
+    ctx = _lib.default_context()
+    L = _lib.lib()
+    out = np.empty((c, h, w), dtype=np.int32)
+    meta = np.empty((rows, 8), dtype=np.int32)
+    st = L.spiht_decode_with_metadata_i32(ctx.handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w,
+                                          ll_h, ll_w, C.c_void_p(topv.ctypes.data), C.c_void_p(oth.ctypes.data),
+                                          len(levels), C.c_void_p(out.ctypes.data), C.c_void_p(meta.ctypes.data))
+    _lib.check(st)
+    return out, meta

@@ -199,9 +199,28 @@ def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSetti
     ll_h, ll_w = slices[0][1].stop, slices[0][2].stop
 
     if return_metadata:
-        raise NotImplementedError("return_metadata=True needs decode_with_metadata (SURVEY.md 8 f-1)")
-    rec_arr = spiht_rs.decode(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w)
-    return dict(rec_arr=rec_arr, slices=slices, spiht_metadata=None, h=h, w=w, level=level)
+        # wrapper:232-250.  The reference passes `slice.start` as is, which is None for the 'a' axes of
+        # pywt.coeffs_to_array's slices (and PyO3 then refuses it); `or 0` is what :234-235 does for the top slice.
+        top_slice = [
+            (slices[0][1].start or 0, slices[0][1].stop),
+            (slices[0][2].start or 0, slices[0][2].stop),
+        ]
+        other_slices = []
+        for slice_level in slices[1:]:
+            slice_filters = []
+            for filter_key in ["da", "ad", "dd"]:
+                slice_filter = slice_level[filter_key]
+                slice_filters.append([
+                    (slice_filter[1].start or 0, slice_filter[1].stop),
+                    (slice_filter[2].start or 0, slice_filter[2].stop),
+                ])
+            other_slices.append(slice_filters)
+        rec_arr, spiht_metadata = spiht_rs.decode_with_metadata(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w,
+                                                                top_slice, other_slices)
+    else:
+        rec_arr = spiht_rs.decode(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w)
+        spiht_metadata = None
+    return dict(rec_arr=rec_arr, slices=slices, spiht_metadata=spiht_metadata, h=h, w=w, level=level)
 
 
 def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settings: SpihtSettings, slices=None):
