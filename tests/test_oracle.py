@@ -179,3 +179,36 @@ def test_dwt_front_and_back_half_match_reference_wrapper(oracle):
         assert np.abs(ri - cs["rec_img"]).max() < 1e-13
         n += 1
     assert n >= 10
+
+
+def test_decode_with_metadata_restatement(oracle):
+    """encoder_decoder.rs:631-841.  No expected rows exist in the reference (parity unpinned): check what its own
+    tests check (:929-966, the decoded array) plus the invariants the doc comment (:616-630) states."""
+    rng = np.random.default_rng(42)
+    for (c, h, w), lv in (((4, 32, 32), 4), ((1, 8, 8), 2)):
+        top = [(0, h // 2), (0, w // 2)]  # Slices::new_basic (:529-578)
+        other = [[[(0, h // 2), (w // 2, w)], [(h // 2, h), (0, w // 2)], [(h // 2, h), (w // 2, w)]]] * lv
+        x = rng.normal(0, 16, (c, h, w)).astype(np.int32)
+        data, n = oracle.encode(x, 2, 2, 10000000)
+        rec, meta = oracle.decode_with_metadata(data, n, c, h, w, 2, 2, top, other)
+        assert np.array_equal(rec, x) and np.array_equal(rec, oracle.decode(data, n, c, h, w, 2, 2))
+        assert meta.shape == (8 * len(data) + 1, 8)
+        bits = oracle.bytes_to_bits(data)
+        used = int(np.nonzero(meta.any(axis=1))[0].max()) + 1
+        m = meta[:used]
+        assert m[:, 0].min() >= 0 and m[:, 0].max() <= 6
+        assert (np.diff(m[:, 6]) <= 0).all() and m[0, 6] == n and m[-1, 6] == 0   # planes count down to 0
+        assert (m[m[:, 4] == 0][:, 5] == lv).all()                                  # LL rows sit at depth == level
+        assert set(np.unique(m[:, 3]).tolist()) == set(range(c))
+        # a sign row (action 1 / 4) always follows a set significance bit (action 0 / 3) of the same coefficient
+        sign_rows = np.nonzero((m[:, 0] == 1) | (m[:, 0] == 4))[0]
+        assert (bits[sign_rows - 1] == 1).all()
+        assert np.array_equal(m[sign_rows][:, 1:6], m[sign_rows - 1][:, 1:6])
+        # the value column is zero until the coefficient is found and is what refinement (action 6) then updates
+        assert (m[np.isin(m[:, 0], (0, 1, 3, 4))][:, 7] == 0).all()
+        assert (m[m[:, 0] == 6][:, 7] != 0).all()
+    # truncated stream: the row after the last bit describes the operation left waiting
+    rec, meta = oracle.decode_with_metadata(data[:3], n, c, h, w, 2, 2, top, other)
+    assert meta.shape == (25, 8) and meta[24].any()
+    with pytest.raises(oracle.OraclePanic):
+        oracle.decode_with_metadata(data, n, c, h, w, 2, 2, top, other[:1])  # tree deeper than `level` (:603)
