@@ -53,9 +53,12 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU baseline codes (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: encode of step i+1 (stream A) overlaps decode of step i (stream B), double-buffered streams. "
-                         "Measured: +6 %% (28.1 vs 29.7 ms/step): the decoder slows from 12.6 to 18 ms when the HBM is "
-                         "saturated by the other stream; restricting the streams to disjoint CU sets changed nothing")
+                    help="1: steps are software-pipelined over two contexts -- the HBM-bound halves (DWT + pyramid of step "
+                         "i+1, inverse DWT of step i-1) run while the list coder works on step i "
+                         "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  Measured: "
+                         "25.3 vs 30.0 ms/step (+19 %% images/s), but co-running kernels slow each other (list decoder "
+                         "x1.5-1.8, DWT x1.4: tools/corun.py), so the DWT's own roofline fraction drops from 0.58 to 0.42.  "
+                         "0 (default): every step runs its stages back to back on one stream, each kernel with the whole GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -126,26 +129,26 @@ def main():
         codecs[k].decode_device(out_ptr + a * slot, d_nbytes.ptr + a * 8, maxn_ptr + a, b - a, d_rec_img.ptr + a * rec_b)
 
     pipe = None
-    if args.pipeline and dist is None:
-        # software pipeline over steps: stream A encodes step i+1 while stream B decodes step i (double-buffered streams)
-        ctx_b = _lib.Context(local_rank)
-        codec_b = BatchCodec(C_IMG, H, W, SpihtSettings(WAVELET, QSCALE, MODE), LEVEL, max_bits, ctx=ctx_b)
-        ctxs.append(ctx_b)
-        d_out2 = DeviceArray(ctx, (B, slot), np.uint8)
-        d_nbits2 = DeviceArray(ctx, (B,), np.uint64)
-        d_maxn2 = DeviceArray(ctx, (B,), np.uint8)
-        d_nbytes2 = DeviceArray(ctx, (B,), np.uint64)
-        pipe = {"i": 0, "bufs": [(out_ptr, nbits_ptr, maxn_ptr, d_nbytes.ptr), (d_out2.ptr, d_nbits2.ptr, d_maxn2.ptr, d_nbytes2.ptr)]}
+    if args.pipeline and K == 1:
+        # The HBM-bound halves (DWT+pyramid of step i+1, zero-fill, inverse DWT of step i-1) run on context H while
+        # context L list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).
+        from spiht_amd.batch import OverlappedCodec
+        pipe = OverlappedCodec(codec, B)
+        ctxs.append(pipe.L)
+        gather_hook = None
+        if dist is not None:
+            # the stream gather rides on L's stream between the encoder's and the decoder's list kernels
+            l_stream = torch.cuda.ExternalStream(pipe.L.stream_ptr(), device=torch.device("cuda", local_rank))
+
+            def gather_hook(_ctx_l):
+                with torch.cuda.stream(l_stream):
+                    dist.all_gather_into_tensor(gathered, out_t)
+                    dist.all_gather_into_tensor(g_nbits, nbits_t)
+                    dist.all_gather_into_tensor(g_maxn, maxn_t)
 
     def step():
         if pipe is not None:
-            o, nb, mn, nby = pipe["bufs"][pipe["i"] & 1]
-            pipe["i"] += 1
-            codec.encode_device(d_img.ptr, B, o, nb, mn)          # stream A
-            ctx_b.wait_on(ctx)                                     # decode(i) after encode(i)
-            ctx.wait_on(ctx_b)                                     # encode(i+1) after decode(i-1): same stream buffers
-            codec_b.nbits_to_nbytes(nb, B, nby)                    # stream B
-            codec_b.decode_device(o, nby, mn, B, d_rec_img.ptr)
+            pipe.submit(d_img.ptr, out_ptr, nbits_ptr, maxn_ptr, d_nbytes.ptr, d_rec_img.ptr, between=gather_hook)
             return
         # every call below only queues kernels on the chunk's own stream
         if dist is None:
@@ -167,6 +170,8 @@ def main():
                 dec_chunk(k)
 
     def sync_all():
+        if pipe is not None:
+            pipe.flush()  # the inverse transform of the last step (inside the timed region)
         for cx in ctxs:
             cx.synchronize()
         if dist is not None:
@@ -278,7 +283,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": "cfg2 image (1920x1080 RGB, bior2.2 reflect level 7, q=50, 0.5 bpp) x %d per GPU "
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
-                       "images_per_gpu": B, "streams": K, "images_per_launch": per_launch, "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
+                       "images_per_gpu": B, "streams": K, "images_per_launch": per_launch,
+                       "schedule": ("steps software-pipelined over two contexts: HBM-bound passes of steps i+1 / i-1 run "
+                                    "while step i is list-coded" if pipe is not None else "stages back to back"), "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]]},
             "roofline": {"bound": "hbm", "kernel": "k_dwt_level<6> (forward DWT level 1, fused quantise)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -55,6 +55,16 @@ int spiht_ctx_synchronize(spiht_ctx *ctx);
  * device) for everything queued on `other` before it.  Lets one context's stream encode step i+1 while another
  * decodes step i. */
 int spiht_ctx_wait_on(spiht_ctx *ctx, spiht_ctx *other);
+/* Finer-grained ordering: an event marks the point a context's queue has reached (spiht_event_record); work queued on
+ * another context after spiht_ctx_wait_event starts only once that point has been passed.  Neither call blocks the host. */
+typedef struct spiht_event spiht_event;
+int spiht_event_create(spiht_ctx *ctx, spiht_event **out);
+void spiht_event_destroy(spiht_event *ev);
+int spiht_event_record(spiht_event *ev, spiht_ctx *ctx);
+int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *ev);
+/* The context's HIP stream (*stream is a hipStream_t) so a caller can queue its own work -- e.g. the RCCL gather of
+ * the streams between encode and decode -- in order with the library's. */
+int spiht_ctx_stream(spiht_ctx *ctx, void **stream);
 /* Stage timing: when enabled, HIP events bracket each kernel group of the next calls
  * (on the context's own stream); spiht_ctx_get_timing returns accumulated ms and launches. */
 int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled);
@@ -166,6 +176,25 @@ int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B
  * that index, 0 = empty/zero; only nodes with offspring are written) and d_maxabs uint32 [B]. */
 int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
                             int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs);
+
+/* The two halves of each direction on their own (device pointers, asynchronous).  The transform + pyramid half is
+ * HBM-bound, the list-coding half is latency-bound and leaves the HBM idle, so a caller that keeps several batches in
+ * flight runs them on two contexts ordered with events (bench.py):
+ *   spiht_dwt_pyramid_batch_f64   pixels -> coefficients + D/L pyramid + max|coef|   (front half of encode_image)
+ *   spiht_encode_lists_batch_i32  coefficients + pyramid -> streams                  (back half; = k_encode)
+ *   spiht_decode_lists_batch_i32  streams -> coefficients; d_out must be ZERO-FILLED by the caller (spiht_dev_memset)
+ *   spiht_dequant_idwt_batch_f64  coefficients -> pixels                             (above)
+ * Results are identical to the fused entry points. */
+int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                int32_t *d_coeffs, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs);
+int spiht_encode_lists_batch_i32(spiht_ctx *ctx, const int32_t *d_x, const uint8_t *d_dmsb, const uint8_t *d_lmsb,
+                                 const uint32_t *d_maxabs, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
+                                 int64_t ll_w, uint64_t max_bits, uint8_t *d_out, uint64_t slot_stride,
+                                 uint64_t *d_nbits, uint8_t *d_max_n);
+int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
+                                 const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
+                                 int64_t ll_w, int32_t *d_out_zeroed);
 
 /* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
  * counts the decoder takes, without a host round trip. */

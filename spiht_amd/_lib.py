@@ -33,7 +33,9 @@ _lib_lock = threading.Lock()
 # every symbol include/spiht_hip.h declares
 SYMBOLS = [
     "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
-    "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
+    "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_event_create", "spiht_event_destroy", "spiht_event_record",
+    "spiht_ctx_wait_event", "spiht_ctx_stream", "spiht_dwt_pyramid_batch_f64", "spiht_encode_lists_batch_i32",
+    "spiht_decode_lists_batch_i32", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
     "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
@@ -66,6 +68,15 @@ def lib():
         L.spiht_ctx_destroy.restype = None
         L.spiht_ctx_synchronize.argtypes = [vp]
         L.spiht_ctx_wait_on.argtypes = [vp, vp]
+        L.spiht_event_create.argtypes = [vp, C.POINTER(vp)]
+        L.spiht_event_destroy.argtypes = [vp]
+        L.spiht_event_destroy.restype = None
+        L.spiht_event_record.argtypes = [vp, vp]
+        L.spiht_ctx_wait_event.argtypes = [vp, vp]
+        L.spiht_ctx_stream.argtypes = [vp, C.POINTER(vp)]
+        L.spiht_dwt_pyramid_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]
+        L.spiht_encode_lists_batch_i32.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, u64, vp, u64, vp, vp]
+        L.spiht_decode_lists_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
         L.spiht_ctx_set_timing.argtypes = [vp, i32]
         L.spiht_ctx_reset_timing.argtypes = [vp]
         L.spiht_ctx_stage_name.restype = C.c_char_p
@@ -143,6 +154,23 @@ class Context:
     def synchronize(self):
         check(self._lib.spiht_ctx_synchronize(self.handle))
 
+    def stream_ptr(self):
+        """the context's hipStream_t as an integer (e.g. for torch.cuda.ExternalStream)"""
+        p = C.c_void_p()
+        check(self._lib.spiht_ctx_stream(self.handle, C.byref(p)))
+        return p.value or 0
+
+    def record(self, event=None):
+        """mark the point this context's queue has reached; returns the Event (a new one unless given)"""
+        if event is None:
+            event = Event(self)
+        check(self._lib.spiht_event_record(event.handle, self.handle))
+        return event
+
+    def wait_event(self, event):
+        """work queued on this context from now on starts only after the recorded point"""
+        check(self._lib.spiht_ctx_wait_event(self.handle, event.handle))
+
     # stage timing (HIP events on the context's stream)
     def set_timing(self, on):
         check(self._lib.spiht_ctx_set_timing(self.handle, 1 if on else 0))
@@ -175,6 +203,24 @@ class Context:
 
     def memset(self, dptr, value, nbytes):
         check(self._lib.spiht_dev_memset(self.handle, C.c_void_p(dptr), int(value), int(nbytes)))
+
+
+class Event:
+    """spiht_event: a point in one context's queue that other contexts can wait for (device-side)."""
+
+    def __init__(self, ctx):
+        self._lib = lib()
+        h = C.c_void_p()
+        check(self._lib.spiht_event_create(ctx.handle, C.byref(h)))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self._lib.spiht_event_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 _ctxs = {}

@@ -464,6 +464,11 @@ static int alloc_lists(spiht_ctx *ctx, const ListCaps &caps, int want_slots, boo
     return SPIHT_OK;
 }
 
+static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, const uint8_t *d_dmsb,
+                               const uint8_t *d_lmsb, const uint32_t *d_maxabs, int B, uint64_t max_bits,
+                               const ListCaps &caps, int nslots, const ListPtrs &lp, uint8_t *d_out, uint64_t slot_stride,
+                               uint64_t *d_nbits, uint8_t *d_maxn);
+
 // Encode B device-resident coefficient arrays.  max_bits already validated; queues work on ctx->stream.
 static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int B, uint64_t max_bits_in, uint8_t *d_out,
                          uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false) {
@@ -490,6 +495,16 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
         StageTimer t(ctx, ST_PYRAMID);
         LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, ctx->stream));
     }
+    return encode_lists_device(ctx, g, d_x, (const uint8_t *)ctx->dmsb.p, (const uint8_t *)ctx->lmsb.p,
+                               (const uint32_t *)ctx->maxabs.p, B, max_bits, caps, nslots, lp, d_out, slot_stride, d_nbits,
+                               d_maxn);
+}
+
+// the list-coding half of the encoder: coefficient arrays + their significance pyramid -> streams
+static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, const uint8_t *d_dmsb,
+                               const uint8_t *d_lmsb, const uint32_t *d_maxabs, int B, uint64_t max_bits,
+                               const ListCaps &caps, int nslots, const ListPtrs &lp, uint8_t *d_out, uint64_t slot_stride,
+                               uint64_t *d_nbits, uint8_t *d_maxn) {
     EncArgs a;
     memset(&a, 0, sizeof(a));
     a.g = g;
@@ -497,9 +512,9 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
     a.B = B;
     a.nslots = nslots;
     a.x = d_x;
-    a.dmsb = (const uint8_t *)ctx->dmsb.p;
-    a.lmsb = (const uint8_t *)ctx->lmsb.p;
-    a.maxabs = (const uint32_t *)ctx->maxabs.p;
+    a.dmsb = d_dmsb;
+    a.lmsb = d_lmsb;
+    a.maxabs = d_maxabs;
     a.max_bits = max_bits;
     a.out = d_out;
     a.slot_stride = slot_stride;
@@ -517,7 +532,8 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
 
 static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, uint64_t slot_stride,
                          const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out,
-                         uint32_t *d_tr_ent = nullptr, uint8_t *d_tr_act = nullptr, uint64_t tr_stride = 0) {
+                         uint32_t *d_tr_ent = nullptr, uint8_t *d_tr_act = nullptr, uint64_t tr_stride = 0,
+                         bool zero_out = true) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if (slot_stride * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
     ListCaps caps;
@@ -525,7 +541,7 @@ static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, u
     int nslots = 0;
     ListPtrs lp;
     CHK(alloc_lists(ctx, caps, std::min(B, ctx->num_cu * 8), true, &nslots, &lp));
-    {
+    if (zero_out) {
         StageTimer t(ctx, ST_MEMSET);
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * g.n * 4, ctx->stream));
     }
@@ -1061,6 +1077,135 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
                         d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
     }
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
+}
+
+// ------------------------------------------------------------------------------------------------
+// the two halves of each direction on their own, so a caller can run the HBM-bound half of one batch on one
+// context while another context list-codes a different batch (bench.py)
+// ------------------------------------------------------------------------------------------------
+
+extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                           int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                           int32_t *d_coeffs, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs) {
+    if (!ctx || !d_img || !d_coeffs || !d_dmsb || !d_lmsb || !d_maxabs) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    Geom g;
+    CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int chunk = batch_chunk(g);
+    HIPCHK(hipMemsetAsync(d_maxabs, 0, (size_t)B * 4, ctx->stream));
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        int32_t *co = d_coeffs + (size_t)b0 * g.n;
+        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
+                        d_maxabs + b0));
+        StageTimer t(ctx, ST_PYRAMID);
+        LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, ctx->stream));
+    }
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_encode_lists_batch_i32(spiht_ctx *ctx, const int32_t *d_x, const uint8_t *d_dmsb,
+                                            const uint8_t *d_lmsb, const uint32_t *d_maxabs, int64_t B, int64_t c,
+                                            int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, uint64_t max_bits_in,
+                                            uint8_t *d_out, uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n) {
+    if (!ctx || !d_x || !d_dmsb || !d_lmsb || !d_maxabs || !d_out || !d_nbits || !d_max_n || B < 0) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (B == 0) return SPIHT_OK;
+    if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;
+    ListCaps caps;
+    list_caps(g, std::min<uint64_t>(max_bits, slot_stride * 8), &caps, nullptr);
+    const int chunk = batch_chunk(g);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        int nb = (int)std::min<int64_t>(chunk, B - b0);
+        int nslots = 0;
+        ListPtrs lp;
+        CHK(alloc_lists(ctx, caps, std::min(nb, ctx->num_cu), false, &nslots, &lp));
+        {
+            StageTimer t(ctx, ST_MEMSET);
+            HIPCHK(hipMemsetAsync(d_out + (size_t)b0 * slot_stride, 0, (size_t)nb * slot_stride, ctx->stream));
+        }
+        CHK(encode_lists_device(ctx, g, d_x + (size_t)b0 * g.n, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n,
+                                d_maxabs + b0, nb, max_bits, caps, nslots, lp, d_out + (size_t)b0 * slot_stride, slot_stride,
+                                d_nbits + b0, d_max_n + b0));
+    }
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
+                                            const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c,
+                                            int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, int32_t *d_out_zeroed) {
+    if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_out_zeroed || B < 0) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false));
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// events: ordering between contexts at a finer grain than spiht_ctx_wait_on
+// ------------------------------------------------------------------------------------------------
+struct spiht_event {
+    int device;
+    hipEvent_t ev;
+};
+
+// the context's HIP stream (a hipStream_t), for callers that put their own work (e.g. an RCCL collective) in order
+// with the library's
+extern "C" int spiht_ctx_stream(spiht_ctx *ctx, void **stream) {
+    if (!ctx || !stream) return SPIHT_ERR_ARG;
+    *stream = (void *)ctx->stream;
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_event_create(spiht_ctx *ctx, spiht_event **out) {
+    if (!ctx || !out) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    spiht_event *e = new spiht_event;
+    e->device = ctx->device;
+    hipError_t r = hipEventCreateWithFlags(&e->ev, hipEventDisableTiming);
+    if (r != hipSuccess) {
+        delete e;
+        g_hip_err = std::string("hipEventCreateWithFlags: ") + hipGetErrorString(r);
+        return SPIHT_ERR_HIP;
+    }
+    *out = e;
+    return SPIHT_OK;
+}
+extern "C" void spiht_event_destroy(spiht_event *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipEventDestroy(e->ev);
+    delete e;
+}
+// marks the point reached by the work queued on ctx so far
+extern "C" int spiht_event_record(spiht_event *e, spiht_ctx *ctx) {
+    if (!e || !ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipEventRecord(e->ev, ctx->stream));
+    return SPIHT_OK;
+}
+// work queued on ctx after this call starts only when the recorded point has been reached
+extern "C" int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *e) {
+    if (!e || !ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, e->ev, 0));
+    return SPIHT_OK;
 }
 
 extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes) {

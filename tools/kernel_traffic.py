@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""HBM traffic of any kernel of the path from rocprofv3 PMC counters (separate --pmc passes; FETCH_SIZE doubled on
+gfx950 as MI355X_MICROARCH.md prescribes).  usage: kernel_traffic.py <stage of prof_stage.py> <kernel substring> [batch]
+Prints bytes per image, averaged over the launches of that kernel."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stage, ksub = sys.argv[1], sys.argv[2]
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+out = {"stage": stage, "kernel": ksub, "images_per_launch": B}
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    subprocess.check_call(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                           "python3", os.path.join(ROOT, "tools", "prof_stage.py"), stage, str(B), "2"],
+                          cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    vals = {}
+    for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            if ksub in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                vals.setdefault(r["Dispatch_Id"], 0.0)
+                vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
+    out[counter + "_KiB_per_launch"] = sum(vals.values()) / max(len(vals), 1)
+    out["launches"] = len(vals)
+out["read_bytes_per_image"] = out["FETCH_SIZE_KiB_per_launch"] * 1024 * 2 / B
+out["write_bytes_per_image"] = out["WRITE_SIZE_KiB_per_launch"] * 1024 / B
+print(json.dumps(out))

@@ -30,10 +30,21 @@ d_rec = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
 codec.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
 codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
 vp = C.c_void_p
-for _ in range(2):
+HOG = len(sys.argv) > 2 and sys.argv[2] == "hog"  # run the decoder while a second stream saturates HBM with forward DWTs
+if HOG:
+    ctx2 = _lib.Context(0)
+    d_coef = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
+    wid, mid = L.spiht_wavelet_id(b"bior2.2"), L.spiht_mode_id(b"reflect")
+for it in range(2):
+    if HOG and it == 1:
+        for _ in range(4):
+            _lib.check(L.spiht_dwt_quant_batch_f64(ctx2.handle, vp(d_img.ptr), B, C_IMG, H, W, wid, mid, LEVEL, 50.0, None,
+                                                   vp(d_coef.ptr)))
     _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B,
                                         C_IMG, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], vp(d_rec.ptr)))
 ctx.synchronize()
+if HOG:
+    ctx2.synchronize()
 words = (C.c_uint32 * 64)()
 L.spiht_debug_words.argtypes = [vp, vp]
 _lib.check(L.spiht_debug_words(ctx.handle, words))
