@@ -27,7 +27,9 @@
 #define DEC_NW 8            // wavefronts per workgroup: 1 sequencer + (DEC_NW-1) workers
 #endif
 #define DEC_NWK (DEC_NW - 1)
-#define DEC_RING (4 * DEC_NW)  // windows in flight between sequencer and workers
+#ifndef DEC_RING
+#define DEC_RING (8 * DEC_NW)  // windows in flight between sequencer and workers (4*NW measured 4 % slower)
+#endif
 #define DEC_TAIL 16
 #define SEQ_OPEN 0xFFFFFFFFu
 #define SPIN_LIMIT (1u << 24)  // bound on every LDS spin (about a second): a protocol bug must not hang the GPU
@@ -250,18 +252,27 @@ __device__ __forceinline__ uint32_t stream_word(const BitSrc &bs, uint32_t wi) {
 }
 
 // 64 consecutive 64-bit stream words, one per lane: the sequencer fetches its windows with v_readlane
+// (a chunk serves 63 windows: window k also needs word k+1).  The chunk after the current one is loaded at the same
+// time and only moved into place 63 windows later, so its latency is never waited for inside a pass.
 struct RegChunk {
-    uint64_t v;
+    uint64_t v, vn;    // current chunk, next chunk (words base64+63 ...)
     uint32_t base64;
     uint32_t valid;
 };
+__device__ __forceinline__ uint64_t stream_word64(const BitSrc &bs, uint32_t w64) {
+    return (uint64_t)stream_word(bs, 2 * w64) | ((uint64_t)stream_word(bs, 2 * w64 + 1) << 32);
+}
 __device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane, uint64_t &lo,
                                        uint64_t &hi) {
     if (!rc.valid || widx < rc.base64 || widx + 1 >= rc.base64 + 64) {
-        const uint32_t w0 = 2 * (widx + lane);
-        rc.v = (uint64_t)stream_word(bs, w0) | ((uint64_t)stream_word(bs, w0 + 1) << 32);
+        if (rc.valid && widx == rc.base64 + 63) {
+            rc.v = rc.vn;  // prefetched 63 windows ago
+        } else {
+            rc.v = stream_word64(bs, widx + lane);
+        }
         rc.base64 = widx;
         rc.valid = 1;
+        rc.vn = stream_word64(bs, widx + 63 + lane);
     }
     const uint32_t k = widx - rc.base64;
     lo = readlane64(rc.v, k);
@@ -301,17 +312,18 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
-__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq, const Item &it, uint32_t lane) {
+__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, const Item &it, uint32_t lane) {
     constexpr uint32_t HALF = DEC_RING / 2;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_io);  // uniform: keep it in an SGPR
     if (seq >= DEC_RING && (seq % HALF) == 0) {
         const uint32_t lim = seq - HALF;  // items [0, lim) must be done
-        for (uint32_t w = 0; w < DEC_NWK; w++) {
-            const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
-            uint32_t spins = 0;
-            while (lds_load(&sh.wdone[w]) < need) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
-            }
+        // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
+        const uint32_t w = lane < DEC_NWK ? lane : 0u;
+        const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
+        uint32_t spins = 0;
+        while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
         }
     }
     const uint32_t w0 = it.kind | (it.pos0 << 8) | (it.pos1 << 16) | (it.cin << 24) | (it.first << 25);
@@ -321,10 +333,12 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq, const 
         q[0] = make_uint4(w0, it.Wb, it.e_start, it.kind ? it.b_ret : it.m_rem);
         q[1] = make_uint4(it.b_lsp, it.b_lip, (uint32_t)it.lo, (uint32_t)(it.lo >> 32));
         q[2] = make_uint4((uint32_t)it.hi, (uint32_t)(it.hi >> 32), (uint32_t)it.fm, (uint32_t)(it.fm >> 32));
-        asm volatile("" ::: "memory");
-        *(volatile uint32_t *)&slot->ready = seq + 1;
+        asm volatile("" ::: "memory");  // compiler order only: the hardware keeps one wavefront's LDS writes in order
+        // (a relaxed workgroup-scope atomic stays a ds_write; a volatile store through the generic pointer became a
+        // flat_store + s_waitcnt vmcnt(0) on the sequencer's critical path)
+        __hip_atomic_store(&slot->ready, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    seq++;
+    seq_io = seq + 1;
 }
 
 __device__ __forceinline__ Item slot_unpack(const Slot &s) {
@@ -565,9 +579,14 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
     for (;;) {
         bool got = false;
         uint32_t spins = 0;
-        volatile uint32_t *rdy = &sh.ring[myk % DEC_RING].ready;
+        uint32_t *rdy = &sh.ring[myk % DEC_RING].ready;
         for (;;) {
-            if (*rdy == myk + 1) { got = true; break; }
+            // relaxed workgroup-scope load = plain ds_read (a volatile read through the generic pointer is a flat load)
+            if (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == myk + 1) {
+                asm volatile("" ::: "memory");  // the item is read after its flag (hardware: one wave's LDS reads are in order)
+                got = true;
+                break;
+            }
             const uint32_t pe = lds_load(&sh.phase_end[par]);
             if (pe != SEQ_OPEN && pe <= myk) break;
             __builtin_amdgcn_s_sleep(1);
@@ -644,7 +663,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         uint32_t myk = wave ? wave - 1 : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
         RegChunk rc;
-        rc.v = 0; rc.base64 = 0; rc.valid = 0;
+        rc.v = 0; rc.vn = 0; rc.base64 = 0; rc.valid = 0;
 #ifdef DEC_PROF
         uint64_t pf[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
@@ -823,18 +842,53 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 const uint32_t seq0 = seq;  // every wave enters the phase with seq == head
                 if (wave == 0) {
                     uint32_t i = 0, dn = 0, first = 1;
-                    // type mask of queue entries [Ebase, Ebase+64): bit = type A with offspring
+                    // Every value the walk depends on is wave-uniform; v_readfirstlane tells hipcc so (values that came
+                    // from LDS or global memory are otherwise kept in VGPRs and every branch on them goes through EXEC).
+#define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+                    uint32_t sP = RFL(P), sSeq = RFL(seq);
+                    const uint32_t cur_len_v = cur_len;
+                    const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
+                    const uint32_t sLsp = RFL(lsp_len), sLip = RFL(lip_len), sRet = RFL(ret_len);
+                    // Type mask of queue entries [Ebase, Ebase+64): bit = type A with offspring.  The masks of 64 chunks
+                    // (4096 entries) are built at once, 16 coalesced loads in flight at a time, and kept one per lane
+                    // in TAv; moving on to the next chunk is then two v_readlane instead of a load the walk would
+                    // have to wait for (a rotating register prefetch does not work: hipcc waits for the newest load
+                    // before it moves the older registers along).
                     uint32_t Ebase = 0;
-                    uint32_t ent = lane < cur_len ? cur[lane] : 0u;
-                    uint32_t ent_nx = (64 + lane) < cur_len ? cur[64 + lane] : 0u;
-                    uint64_t TA = __ballot((ent & ENT_A) && !(ent & ENT_LEAF));
-                    while (i < cur_len) {
-                        if (P >= nbits) {
-                            if (META && lane == 0) tr_put(tr, nbits, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
+                    const uint32_t last_e = sCur - 1;
+                    uint64_t TAv = 0;        // lane l: mask of chunk blk0 + l
+                    uint32_t blk0 = 0;       // first chunk of the block held in TAv
+                    auto build_block = [&](uint32_t c0) {
+                        const uint32_t nch_all = (sCur + 63u) >> 6;
+                        const uint32_t nch = (nch_all - c0) < 64u ? (nch_all - c0) : 64u;
+                        TAv = 0;
+                        for (uint32_t t0 = 0; t0 < nch; t0 += 16) {
+                            uint32_t e[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const uint32_t ix = ((c0 + t0 + (uint32_t)u) << 6) + lane;
+                                e[u] = cur[ix < last_e ? ix : last_e];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                const uint32_t base = (c0 + t0 + (uint32_t)u) << 6;
+                                uint64_t m = __ballot((e[u] & ENT_A) && !(e[u] & ENT_LEAF));
+                                const uint32_t left = base < sCur ? sCur - base : 0u;
+                                if (left < 64u) m &= (1ull << left) - 1ull;
+                                if (lane == t0 + (uint32_t)u) TAv = m;
+                            }
+                        }
+                        blk0 = c0;
+                    };
+                    build_block(0);
+                    uint64_t TA = readlane64(TAv, 0);
+                    while (i < sCur) {
+                        if (sP >= sNb) {
+                            if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
                             dn = 1;
                             break;
                         }
-                        const uint32_t widx = P >> 6, Wb = widx << 6, pos0 = P & 63u;
+                        const uint32_t widx = sP >> 6, Wb = widx << 6, pos0 = sP & 63u;
                         uint32_t pos = pos0;
                         uint64_t lo, hi;
 #ifdef DEC_PROF
@@ -854,7 +908,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             }
                             LAv = 5 + ns;
                         }
-                        const uint32_t vb = (nbits - Wb) < 64u ? (nbits - Wb) : 64u;
+                        const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
 #ifdef DEC_PROF
@@ -864,12 +918,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         for (;;) {  // one pass per chunk of 64 queue entries met inside this window
                             if (i >= Ebase + 64) {
                                 Ebase += 64;
-                                ent = ent_nx;
-                                ent_nx = (Ebase + 64 + lane) < cur_len ? cur[Ebase + 64 + lane] : 0u;
-                                TA = __ballot((ent & ENT_A) && !(ent & ENT_LEAF));
+                                const uint32_t ch = Ebase >> 6;
+                                if (ch >= blk0 + 64) build_block(ch);
+                                TA = readlane64(TAv, ch - blk0);
                             }
                             uint32_t rel = i - Ebase;
-                            const uint32_t nEw = (cur_len - Ebase) < 64u ? (cur_len - Ebase) : 64u;
+                            const uint32_t nEw = (sCur - Ebase) < 64u ? (sCur - Ebase) : 64u;
                             // TA has no bits at or past nEw and `lo` none at or past vb: a candidate is always in range
 #ifdef DEC_HOP_C
                             do {
@@ -932,27 +986,30 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             }
 #endif
                             i = Ebase + rel;
-                            if (pos >= vb || i >= cur_len) break;
+                            if (pos >= vb || i >= sCur) break;
                         }
 #ifdef DEC_PROF
                         pf[13] += __builtin_amdgcn_s_memtime() - th;
 #endif
                         Item it;
                         it.kind = 1; it.Wb = Wb; it.pos0 = pos0; it.pos1 = pos < 64u ? pos : 64u; it.e_start = i0; it.cin = 0;
-                        it.m_rem = 0; it.first = first; it.b_lsp = lsp_len; it.b_lip = lip_len; it.b_nxt = 0; it.b_ret = ret_len;
+                        it.m_rem = 0; it.first = first; it.b_lsp = sLsp; it.b_lip = sLip; it.b_nxt = 0; it.b_ret = sRet;
                         it.lo = lo; it.hi = hi; it.fm = fm;
 #ifdef DEC_PROF
                         const uint64_t tq = __builtin_amdgcn_s_memtime();
 #endif
-                        seq_publish(sh, seq, it, lane);
+                        seq_publish(sh, sSeq, it, lane);
 #ifdef DEC_PROF
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
                         first = 0;
-                        P = Wb + pos;
-                        if (P > nbits) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
+                        sP = Wb + pos;
+                        if (sP > sNb) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
                     }
-                    if (i < cur_len) dn = 1;  // stream exhausted before the queue
+                    if (i < sCur) dn = 1;  // stream exhausted before the queue
+                    P = sP;
+                    seq = sSeq;
+#undef RFL
                     seq_close(sh, par, seq, P, dn, 0, 0, lane);
                 } else {
                     worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,

@@ -58,8 +58,8 @@ def test_decode_rec_array_and_from_rec_arr(oracle):
     assert d["spiht_metadata"] is None and (d["h"], d["w"], d["level"]) == (50, 41, 2)
     im = decode_from_rec_arr(d["rec_arr"], 50, 41, 2, s)
     assert np.array_equal(im, oracle.waverec2_array(oracle.dequantize(ref, 50.0), 50, 41, "bior2.2", 2))
-    with pytest.raises(NotImplementedError):
-        decode_rec_array(enc, s, return_metadata=True)
+    dm = decode_rec_array(enc, s, return_metadata=True)
+    assert np.array_equal(dm["rec_arr"], ref) and dm["spiht_metadata"].shape == (8 * len(enc.encoded_bytes) + 1, 8)
 
 
 def test_colour_model_ipt_self_consistency():
