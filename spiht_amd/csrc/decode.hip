@@ -26,7 +26,15 @@
 #ifndef DEC_NW
 #define DEC_NW 8            // wavefronts per workgroup: 1 sequencer + (DEC_NW-1) workers
 #endif
+#ifdef DEC_SEQ_ALONE  // experiment: wavefront 4 (same SIMD as the sequencer) takes no LIS windows
+#define DEC_NWK (DEC_NW - 2)
+#define DEC_WK(wave) ((wave) < 4 ? (wave) - 1 : (wave) - 2)
+#define DEC_IS_WORKER(wave) ((wave) != 0 && (wave) != 4)
+#else
 #define DEC_NWK (DEC_NW - 1)
+#define DEC_WK(wave) ((wave) - 1)
+#define DEC_IS_WORKER(wave) ((wave) != 0)
+#endif
 #ifndef DEC_RING
 #define DEC_RING (8 * DEC_NW)  // windows in flight between sequencer and workers (4*NW measured 4 % slower)
 #endif
@@ -62,16 +70,21 @@ struct Item {  // one 64-bit stream window of one pass
     uint64_t fm;          // LIS: start positions of fired type-A entries with offspring
 };
 
-// LDS form of an item: 12 payload words (three 16-byte writes by one lane) + the `ready` word, which is written
-// LAST and holds sequence number + 1.
+// LDS form of a LIS window: only what the walk itself produces (one 16-byte write by one lane) + the `ready` word,
+// which is written LAST and holds sequence number + 1.  The windows of a phase are consecutive, so everything else
+// follows from the sequence number and the phase's PhaseInfo; the worker fetches the window's bits itself.
 struct __attribute__((aligned(16))) Slot {
-    uint32_t w0;         // kind | pos0 << 8 | pos1 << 16 | cin << 24 | first << 25
-    uint32_t Wb, e_start;
-    uint32_t m_rem;       // LIP: m_rem;  LIS: b_ret
-    uint32_t b_lsp, b_lip;
-    uint32_t lo0, lo1, hi0, hi1, fm0, fm1;
+    uint32_t fm0, fm1;    // start positions of fired type-A entries with offspring
+    uint32_t e_start;     // index in the queue of the window's first entry
+    uint32_t w3;          // pos0 | pos1 << 8
     uint32_t ready;
     uint32_t pad[3];
+};
+
+struct PhaseInfo {  // written by the sequencer before the first window of a LIS phase (generation)
+    uint32_t seq0;        // sequence number of the phase's first window
+    uint32_t widx0;       // its 64-bit window index in the stream
+    uint32_t b_lsp, b_lip, b_ret;  // list lengths at the start of the phase
 };
 
 struct Chain {  // running list lengths after item k; seq == k+1 once item k published them
@@ -92,6 +105,7 @@ struct DecShared {
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     Slot ring[DEC_RING];
     Chain chain[DEC_RING];
+    PhaseInfo ph;
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
     uint32_t wdone[DEC_NWK];    // items completed per worker
@@ -264,8 +278,12 @@ __device__ __forceinline__ uint64_t stream_word64(const BitSrc &bs, uint32_t w64
 }
 __device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane, uint64_t &lo,
                                        uint64_t &hi) {
-    if (!rc.valid || widx < rc.base64 || widx + 1 >= rc.base64 + 64) {
-        if (rc.valid && widx == rc.base64 + 63) {
+    // uniform values: say so, or the test below is compiled as divergent code on every window
+    const uint32_t rc_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.base64);
+    const uint32_t rc_valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.valid);
+    uint32_t k = widx - rc_base;
+    if (!rc_valid || widx < rc_base || widx + 1 >= rc_base + 64) {
+        if (rc_valid && widx == rc_base + 63) {
             rc.v = rc.vn;  // prefetched 63 windows ago
         } else {
             rc.v = stream_word64(bs, widx + lane);
@@ -273,8 +291,8 @@ __device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t 
         rc.base64 = widx;
         rc.valid = 1;
         rc.vn = stream_word64(bs, widx + 63 + lane);
+        k = 0;
     }
-    const uint32_t k = widx - rc.base64;
     lo = readlane64(rc.v, k);
     hi = readlane64(rc.v, k + 1);
 }
@@ -312,7 +330,8 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
-__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, const Item &it, uint32_t lane) {
+__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, uint64_t fm, uint32_t e_start, uint32_t pos0,
+                                            uint32_t pos1, uint32_t lane) {
     constexpr uint32_t HALF = DEC_RING / 2;
     const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_io);  // uniform: keep it in an SGPR
     if (seq >= DEC_RING && (seq % HALF) == 0) {
@@ -326,13 +345,9 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, con
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
         }
     }
-    const uint32_t w0 = it.kind | (it.pos0 << 8) | (it.pos1 << 16) | (it.cin << 24) | (it.first << 25);
     if (lane == 0) {
         Slot *slot = &sh.ring[seq % DEC_RING];
-        uint4 *q = reinterpret_cast<uint4 *>(slot);
-        q[0] = make_uint4(w0, it.Wb, it.e_start, it.kind ? it.b_ret : it.m_rem);
-        q[1] = make_uint4(it.b_lsp, it.b_lip, (uint32_t)it.lo, (uint32_t)(it.lo >> 32));
-        q[2] = make_uint4((uint32_t)it.hi, (uint32_t)(it.hi >> 32), (uint32_t)it.fm, (uint32_t)(it.fm >> 32));
+        *reinterpret_cast<uint4 *>(slot) = make_uint4((uint32_t)fm, (uint32_t)(fm >> 32), e_start, pos0 | (pos1 << 8));
         asm volatile("" ::: "memory");  // compiler order only: the hardware keeps one wavefront's LDS writes in order
         // (a relaxed workgroup-scope atomic stays a ds_write; a volatile store through the generic pointer became a
         // flat_store + s_waitcnt vmcnt(0) on the sequencer's critical path)
@@ -341,17 +356,21 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, con
     seq_io = seq + 1;
 }
 
-__device__ __forceinline__ Item slot_unpack(const Slot &s) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(&s);
-    const uint4 a = q[0], b = q[1], c = q[2];
+// worker side: the item of sequence number k (its slot has been seen ready)
+__device__ __forceinline__ Item slot_unpack(DecShared &sh, const BitSrc &bs, uint32_t k) {
+    const uint4 a = *reinterpret_cast<const uint4 *>(&sh.ring[k % DEC_RING]);
+    const uint32_t seq0 = sh.ph.seq0;
+    const uint32_t widx = sh.ph.widx0 + (k - seq0);
     Item it;
-    it.kind = a.x & 0xFFu; it.pos0 = (a.x >> 8) & 0xFFu; it.pos1 = (a.x >> 16) & 0xFFu; it.cin = (a.x >> 24) & 1u;
-    it.first = (a.x >> 25) & 1u;
-    it.Wb = a.y; it.e_start = a.z; it.m_rem = a.w; it.b_ret = a.w; it.b_nxt = 0;
-    it.b_lsp = b.x; it.b_lip = b.y;
-    it.lo = (uint64_t)b.z | ((uint64_t)b.w << 32);
-    it.hi = (uint64_t)c.x | ((uint64_t)c.y << 32);
-    it.fm = (uint64_t)c.z | ((uint64_t)c.w << 32);
+    it.kind = 1; it.cin = 0; it.m_rem = 0; it.b_nxt = 0;
+    it.fm = (uint64_t)a.x | ((uint64_t)a.y << 32);
+    it.e_start = a.z;
+    it.pos0 = a.w & 0xFFu; it.pos1 = (a.w >> 8) & 0xFFu;
+    it.first = k == seq0;
+    it.b_lsp = sh.ph.b_lsp; it.b_lip = sh.ph.b_lip; it.b_ret = sh.ph.b_ret;
+    it.Wb = widx << 6;
+    it.lo = stream_word64(bs, widx);
+    it.hi = stream_word64(bs, widx + 1);
     return it;
 }
 
@@ -575,7 +594,8 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
                                              const uint32_t *lip_rd, uint32_t *lip_wr, uint32_t *lip_app,
                                              const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lsp_idx,
                                              int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
-                                             int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr) {
+                                             int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr,
+                                             const BitSrc &bs) {
     for (;;) {
         bool got = false;
         uint32_t spins = 0;
@@ -593,12 +613,8 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
         }
         if (!got) break;
-        const Item it = slot_unpack(sh.ring[myk % DEC_RING]);
-        if (it.kind == 0)
-            work_lip<META>(sh, a, it, lip_rd, lip_wr, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
-        else
-            work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane,
-                           tr);
+        const Item it = slot_unpack(sh, bs, myk);
+        work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
         myk += DEC_NWK;
@@ -660,7 +676,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         uint32_t lip_len = 0, lsp_len = 0, lis_len = 0;
         uint32_t P = 0, cut = 0;
         uint32_t seq = 0;                    // items produced so far (kept in step by every wave at phase ends)
-        uint32_t myk = wave ? wave - 1 : 0;  // worker: sequence number of its next item
+        uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
         RegChunk rc;
         rc.v = 0; rc.vn = 0; rc.base64 = 0; rc.valid = 0;
@@ -991,14 +1007,13 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                         pf[13] += __builtin_amdgcn_s_memtime() - th;
 #endif
-                        Item it;
-                        it.kind = 1; it.Wb = Wb; it.pos0 = pos0; it.pos1 = pos < 64u ? pos : 64u; it.e_start = i0; it.cin = 0;
-                        it.m_rem = 0; it.first = first; it.b_lsp = sLsp; it.b_lip = sLip; it.b_nxt = 0; it.b_ret = sRet;
-                        it.lo = lo; it.hi = hi; it.fm = fm;
 #ifdef DEC_PROF
                         const uint64_t tq = __builtin_amdgcn_s_memtime();
 #endif
-                        seq_publish(sh, sSeq, it, lane);
+                        if (first && lane == 0) {  // before the phase's first slot (same wave: LDS writes stay in order)
+                            sh.ph.seq0 = sSeq; sh.ph.widx0 = widx; sh.ph.b_lsp = sLsp; sh.ph.b_lip = sLip; sh.ph.b_ret = sRet;
+                        }
+                        seq_publish(sh, sSeq, fm, i0, pos0, pos < 64u ? pos : 64u, lane);
 #ifdef DEC_PROF
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
@@ -1011,9 +1026,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     seq = sSeq;
 #undef RFL
                     seq_close(sh, par, seq, P, dn, 0, 0, lane);
-                } else {
+                } else if (DEC_IS_WORKER(wave)) {
                     worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,
-                                       tail_start, n, base_val, wave - 1, lane, tr);
+                                       tail_start, n, base_val, DEC_WK(wave), lane, tr, bs);
                 }
                 PF_ADD(2);
                 __syncthreads();
