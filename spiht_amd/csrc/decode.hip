@@ -26,15 +26,13 @@
 #ifndef DEC_NW
 #define DEC_NW 8            // wavefronts per workgroup: 1 sequencer + (DEC_NW-1) workers
 #endif
-#ifdef DEC_SEQ_ALONE  // experiment: wavefront 4 (same SIMD as the sequencer) takes no LIS windows
+// LIS pass roles: wavefront 0 = sequencer, wavefront 1 = helper (prepares the sequencer's per-window inputs ahead of
+// it), wavefronts 2.. = workers.  (Measured: 5 workers already keep up with the sequencer.)
 #define DEC_NWK (DEC_NW - 2)
-#define DEC_WK(wave) ((wave) < 4 ? (wave) - 1 : (wave) - 2)
-#define DEC_IS_WORKER(wave) ((wave) != 0 && (wave) != 4)
-#else
-#define DEC_NWK (DEC_NW - 1)
-#define DEC_WK(wave) ((wave) - 1)
-#define DEC_IS_WORKER(wave) ((wave) != 0)
-#endif
+#define DEC_WK(wave) ((wave) - 2)
+#define DEC_IS_WORKER(wave) ((wave) >= 2)
+#define DEC_PREP 64   // windows the helper may run ahead of the sequencer (ring in LDS)
+#define DEC_PREP_B 16 // ... which it announces in batches of this many
 #ifndef DEC_RING
 #define DEC_RING (8 * DEC_NW)  // windows in flight between sequencer and workers (4*NW measured 4 % slower)
 #endif
@@ -106,6 +104,12 @@ struct DecShared {
     Slot ring[DEC_RING];
     Chain chain[DEC_RING];
     PhaseInfo ph;
+    // helper -> sequencer: per window, the stream bits and, per window position, the length a fired type-A entry
+    // would have if it started there
+    uint64_t plo[DEC_PREP];
+    uint8_t plav[DEC_PREP][64];
+    uint32_t pprog;             // windows of this phase the helper has prepared
+    uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_PREP_B)
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
     uint32_t wdone[DEC_NWK];    // items completed per worker
@@ -621,6 +625,45 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
     }
 }
 
+// helper loop of one LIS phase (wavefront 1): window j of the phase is stream window widx0 + j
+__device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, uint32_t par, uint32_t widx0, uint32_t lane) {
+    uint64_t v = 0;         // 64 consecutive 64-bit stream words, one per lane (serves 63 windows)
+    uint32_t base = 0, have = 0;
+    for (uint32_t j = 0;; j += DEC_PREP_B) {
+        uint32_t spins = 0;
+        for (;;) {  // room for another batch, or the end of the phase
+            if (lds_load(&sh.phase_end[par]) != SEQ_OPEN) return;
+            if (j + DEC_PREP_B <= lds_load(&sh.sprog) + DEC_PREP) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { sh.bad = 2; return; }
+        }
+#pragma unroll 4
+        for (uint32_t u = 0; u < DEC_PREP_B; u++) {
+            const uint32_t widx = widx0 + j + u;
+            if (!have || widx + 1 >= base + 64) {
+                v = stream_word64(bs, widx + lane);
+                base = widx;
+                have = 1;
+            }
+            const uint32_t k = widx - base;
+            const uint64_t lo = readlane64(v, k), hi = readlane64(v, k + 1);
+            const uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
+            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu, ns = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t s = pl & 1u;
+                pl >>= 1 + s;
+                ns += s;
+            }
+            const uint32_t slot = (j + u) % DEC_PREP;
+            sh.plav[slot][lane] = (uint8_t)(5 + ns);
+            if (lane == 0) sh.plo[slot] = lo;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
+    }
+}
+
 // the sequencer closes a phase: results first, then the slot of the NEXT phase is opened, then this one ends
 __device__ __forceinline__ void seq_close(DecShared &sh, uint32_t par, uint32_t seq, uint32_t P, uint32_t dn, uint32_t lsp,
                                           uint32_t lipl, uint32_t lane) {
@@ -688,6 +731,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         __syncthreads();  // previous image fully finished with the shared state
         if (threadIdx.x == 0) {
             sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.ntail = 0; sh.bad = 0;
+            sh.pprog = 0; sh.sprog = 0;
             for (int w = 0; w < DEC_NWK; w++) sh.wdone[w] = 0;
             for (int r = 0; r < DEC_RING; r++) { sh.chain[r].seq = 0; sh.ring[r].ready = 0; }
         }
@@ -862,6 +906,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     // from LDS or global memory are otherwise kept in VGPRs and every branch on them goes through EXEC).
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
                     uint32_t sP = RFL(P), sSeq = RFL(seq);
+                    const uint32_t widx0s = sP >> 6;  // first window of the phase (the helper starts there too)
+                    uint32_t pknown = 0;              // windows known to be prepared
                     const uint32_t cur_len_v = cur_len;
                     const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
                     const uint32_t sLsp = RFL(lsp_len), sLip = RFL(lip_len), sRet = RFL(ret_len);
@@ -906,24 +952,23 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         }
                         const uint32_t widx = sP >> 6, Wb = widx << 6, pos0 = sP & 63u;
                         uint32_t pos = pos0;
-                        uint64_t lo, hi;
 #ifdef DEC_PROF
                         const uint64_t tw = __builtin_amdgcn_s_memtime();
 #endif
-                        window(bs, rc, widx, lane, lo, hi);
-                        // length of a fired type-A entry starting at window position `lane`
-                        uint32_t LAv;
-                        {
-                            const uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
-                            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu, ns = 0;
-#pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                uint32_t s = pl & 1u;
-                                pl >>= 1 + s;
-                                ns += s;
+                        // the helper wavefront has prepared this window: its bits and, per position, the length a
+                        // fired type-A entry would have there
+                        const uint32_t kw = widx - widx0s;
+                        if (kw >= pknown) {
+                            uint32_t spins = 0;
+                            while ((pknown = RFL(lds_load(&sh.pprog))) <= kw) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
                             }
-                            LAv = 5 + ns;
                         }
+                        const uint32_t pslot = kw % DEC_PREP;
+                        const uint32_t LAv = sh.plav[pslot][lane];
+                        const uint64_t lo_v = sh.plo[pslot];
+                        const uint64_t lo = (uint64_t)RFL((uint32_t)lo_v) | ((uint64_t)RFL((uint32_t)(lo_v >> 32)) << 32);
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
@@ -1018,6 +1063,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
                         first = 0;
+                        if ((kw % DEC_PREP_B) == DEC_PREP_B - 1 && lane == 0)  // lets the helper reuse ring entries
+                            __hip_atomic_store(&sh.sprog, kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         sP = Wb + pos;
                         if (sP > sNb) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
                     }
@@ -1026,12 +1073,15 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     seq = sSeq;
 #undef RFL
                     seq_close(sh, par, seq, P, dn, 0, 0, lane);
+                } else if (wave == 1) {
+                    helper_phase(sh, bs, par, P >> 6, lane);
                 } else if (DEC_IS_WORKER(wave)) {
                     worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,
                                        tail_start, n, base_val, DEC_WK(wave), lane, tr, bs);
                 }
                 PF_ADD(2);
                 __syncthreads();
+                if (threadIdx.x == 0) { sh.pprog = 0; sh.sprog = 0; }  // between the two barriers that end the phase
                 phase++;
                 PF_CNT(8, 1);
                 const uint32_t seq_end = sh.head;
