@@ -916,7 +916,6 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     // in TAv; moving on to the next chunk is then two v_readlane instead of a load the walk would
                     // have to wait for (a rotating register prefetch does not work: hipcc waits for the newest load
                     // before it moves the older registers along).
-                    uint32_t Ebase = 0;
                     const uint32_t last_e = sCur - 1;
                     uint64_t TAv = 0;        // lane l: mask of chunk blk0 + l
                     uint32_t blk0 = 0;       // first chunk of the block held in TAv
@@ -933,17 +932,17 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             }
 #pragma unroll
                             for (int u = 0; u < 16; u++) {
-                                const uint32_t base = (c0 + t0 + (uint32_t)u) << 6;
-                                uint64_t m = __ballot((e[u] & ENT_A) && !(e[u] & ENT_LEAF));
-                                const uint32_t left = base < sCur ? sCur - base : 0u;
-                                if (left < 64u) m &= (1ull << left) - 1ull;
-                                if (lane == t0 + (uint32_t)u) TAv = m;
+                                const uint64_t m = __ballot((e[u] & ENT_A) && !(e[u] & ENT_LEAF));
+                                TAv = (lane == t0 + (uint32_t)u) ? m : TAv;
                             }
                         }
+                        // entries past the end of the queue (clamped loads above): only the queue's last chunk has any
+                        const uint32_t tail = sCur & 63u;
+                        if (tail && nch_all - 1u - c0 < 64u && lane == nch_all - 1u - c0) TAv &= (1ull << tail) - 1ull;
+                        if (lane >= nch) TAv = 0;
                         blk0 = c0;
                     };
                     build_block(0);
-                    uint64_t TA = readlane64(TAv, 0);
                     while (i < sCur) {
                         if (sP >= sNb) {
                             if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
@@ -976,78 +975,58 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         const uint64_t th = __builtin_amdgcn_s_memtime();
                         pf[12] += th - tw;
 #endif
-                        for (;;) {  // one pass per chunk of 64 queue entries met inside this window
-                            if (i >= Ebase + 64) {
-                                Ebase += 64;
-                                const uint32_t ch = Ebase >> 6;
-                                if (ch >= blk0 + 64) build_block(ch);
-                                TA = readlane64(TAv, ch - blk0);
-                            }
-                            uint32_t rel = i - Ebase;
-                            const uint32_t nEw = (sCur - Ebase) < 64u ? (sCur - Ebase) : 64u;
-                            // TA has no bits at or past nEw and `lo` none at or past vb: a candidate is always in range
-#ifdef DEC_HOP_C
-                            do {
-                                const uint64_t cand = lo & ((TA >> rel) << pos);
-                                if (cand == 0) {
-                                    const uint32_t z = (vb - pos) < (nEw - rel) ? (vb - pos) : (nEw - rel);
-                                    rel += z;
-                                    pos += z;
-                                    break;
-                                }
-                                const uint32_t f = (uint32_t)__builtin_ctzll(cand);
-                                fm |= 1ull << f;
-                                PF_CNT(10, 1);
-                                const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)LAv, (int)f);
-                                rel += f - pos + 1;
-                                pos = f + len;
-                            } while (pos < vb && rel < nEw);
-#else
-                            // The same loop, hand-scheduled: this serial chain bounds the whole decoder and hipcc's
-                            // version of it is more than twice as long (uniform conditions routed through VCC/EXEC).
-                            // Relative coordinates keep the dependent chain short: L = bits from the current position on,
-                            // T = type mask from the current entry on, so a candidate is `L & T` (s_and sets SCC), its
-                            // offset d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (two shifts each: a single shift
-                            // count must stay below 64).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and.
+                        // Entries [i, i+64) can be all this window meets (an entry takes at least one bit): their type
+                        // mask is a funnel shift of the masks of chunk i/64 and the next one, both kept in TAv.
+                        uint32_t rel = 0;
+                        {
+                            const uint32_t ch = i >> 6, r0 = i & 63u;
+                            if (ch + 1 >= blk0 + 64) build_block(ch);
+                            const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
+                            uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
+                            uint64_t Lr = lo >> pos, c64;
+                            uint32_t f, dd, len;
+                            // The walk, hand-scheduled: this serial chain bounds the whole decoder and hipcc's version of
+                            // it is more than twice as long (uniform conditions routed through VCC/EXEC).  Relative
+                            // coordinates keep the dependent chain short: L = bits from the current position on, T = type
+                            // mask from the current entry on, so a candidate is `L & T` (s_and sets SCC), its offset
+                            // d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (two shifts each: a single shift count
+                            // must stay below 64).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and, about 100
+                            // cycles (tools/ubench/hop.hip); two hops per trip save the taken branch every other hop.
                             // Four SALU instructions separate the s_add that makes the lane select from v_readlane.
-                            {
-                                uint32_t f, dd, len;
-                                // tell the compiler these wave-uniform values live in SGPRs
-                                rel = (uint32_t)__builtin_amdgcn_readfirstlane((int)rel);
-                                pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
-                                uint64_t Lr = lo >> pos, Tr = TA >> rel, c64;
-                                asm volatile(
-                                    "s_and_b64 %[c], %[L], %[T]\n\t"
-                                    "s_cbranch_scc0 s_hop_done%=\n"
-                                    "s_hop_loop%=:\n\t"
-                                    "s_ff1_i32_b64 %[d], %[c]\n\t"
-                                    "s_add_i32 %[f], %[pos], %[d]\n\t"
-                                    "s_lshr_b64 %[T], %[T], %[d]\n\t"
-                                    "s_lshr_b64 %[L], %[L], %[d]\n\t"
-                                    "s_bitset1_b64 %[fm], %[f]\n\t"
-                                    "s_lshr_b64 %[T], %[T], 1\n\t"
-                                    "v_readlane_b32 %[len], %[LAv], %[f]\n\t"
-                                    "s_add_i32 %[rel], %[rel], %[d]\n\t"
-                                    "s_add_i32 %[rel], %[rel], 1\n\t"
-                                    "s_lshr_b64 %[L], %[L], %[len]\n\t"
-                                    "s_add_i32 %[pos], %[f], %[len]\n\t"
-                                    "s_and_b64 %[c], %[L], %[T]\n\t"
-                                    "s_cbranch_scc1 s_hop_loop%=\n"
-                                    "s_hop_done%=:\n\t"
-                                    : [rel] "+s"(rel), [pos] "+s"(pos), [fm] "+s"(fm), [L] "+s"(Lr), [T] "+s"(Tr), [c] "=&s"(c64),
-                                      [f] "=&s"(f), [d] "=&s"(dd), [len] "=&s"(len)
-                                    : [LAv] "v"(LAv)
-                                    : "scc");
-                                // no candidate left among this chunk's entries / this window's bits: the rest take one bit each
-                                if (pos < vb) {
-                                    const uint32_t z = (vb - pos) < (nEw - rel) ? (vb - pos) : (nEw - rel);
-                                    rel += z;
-                                    pos += z;
-                                }
+#define HOP_BODY                                                \
+    "s_ff1_i32_b64 %[d], %[c]\n\t"                              \
+    "s_add_i32 %[f], %[pos], %[d]\n\t"                          \
+    "s_lshr_b64 %[T], %[T], %[d]\n\t"                           \
+    "s_lshr_b64 %[L], %[L], %[d]\n\t"                           \
+    "s_bitset1_b64 %[fm], %[f]\n\t"                             \
+    "s_lshr_b64 %[T], %[T], 1\n\t"                              \
+    "v_readlane_b32 %[len], %[LAv], %[f]\n\t"                   \
+    "s_add_i32 %[rel], %[rel], %[d]\n\t"                        \
+    "s_add_i32 %[rel], %[rel], 1\n\t"                           \
+    "s_lshr_b64 %[L], %[L], %[len]\n\t"                         \
+    "s_add_i32 %[pos], %[f], %[len]\n\t"                        \
+    "s_and_b64 %[c], %[L], %[T]\n\t"
+                            asm volatile(
+                                "s_and_b64 %[c], %[L], %[T]\n\t"
+                                "s_cbranch_scc0 s_hop_done%=\n"
+                                "s_hop_loop%=:\n\t"
+                                HOP_BODY
+                                "s_cbranch_scc0 s_hop_done%=\n\t"
+                                HOP_BODY
+                                "s_cbranch_scc1 s_hop_loop%=\n"
+                                "s_hop_done%=:\n\t"
+                                : [rel] "+s"(rel), [pos] "+s"(pos), [fm] "+s"(fm), [L] "+s"(Lr), [T] "+s"(Tr), [c] "=&s"(c64),
+                                  [f] "=&s"(f), [d] "=&s"(dd), [len] "=&s"(len)
+                                : [LAv] "v"(LAv)
+                                : "scc");
+#undef HOP_BODY
+                            // no fired type-A entry left among the window's bits: the rest take one bit each
+                            if (pos < vb) {
+                                const uint32_t z = (vb - pos) < (sCur - i - rel) ? (vb - pos) : (sCur - i - rel);
+                                rel += z;
+                                pos += z;
                             }
-#endif
-                            i = Ebase + rel;
-                            if (pos >= vb || i >= sCur) break;
+                            i += rel;
                         }
 #ifdef DEC_PROF
                         pf[13] += __builtin_amdgcn_s_memtime() - th;

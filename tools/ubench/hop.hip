@@ -166,27 +166,27 @@ static void run(const char *name, const uint64_t *dL, const uint64_t *dT, int nw
 
 int main() {
     const int nwin = 256;
-    uint64_t hL[nwin], hT[nwin];
-    srand(1);
-    for (int w = 0; w < nwin; w++) {
-        uint64_t l = 0, t = 0;
-        for (int b = 0; b < 64; b++) {
-            if (rand() % 100 < 45) l |= 1ull << b;
-            if (rand() % 100 < 60) t |= 1ull << b;
-        }
-        hL[w] = l; hT[w] = t;
-    }
     uint64_t *dL, *dT, *dout;
-    CHK(hipMalloc(&dL, sizeof(hL))); CHK(hipMalloc(&dT, sizeof(hT))); CHK(hipMalloc(&dout, 4096 * 32));
-    CHK(hipMemcpy(dL, hL, sizeof(hL), hipMemcpyHostToDevice));
-    CHK(hipMemcpy(dT, hT, sizeof(hT), hipMemcpyHostToDevice));
-    for (int threads : {64, 512})
-        for (int blocks : {1, 256})
-            for (int prio : {0, 1}) {
-                run<0>("V0 current", dL, dT, nwin, threads, blocks, prio, dout);
-                run<1>("V1 two hops per trip", dL, dT, nwin, threads, blocks, prio, dout);
-                run<2>("V2 lean (no rel, T>>d+1)", dL, dT, nwin, threads, blocks, prio, dout);
-                run<3>("V3 no readlane (lower bound)", dL, dT, nwin, threads, blocks, prio, dout);
+    CHK(hipMalloc(&dL, nwin * 8)); CHK(hipMalloc(&dT, nwin * 8)); CHK(hipMalloc(&dout, 4096 * 32));
+    // two densities of fired entries: the slope between them is the cost of one hop, the rest is per-window overhead
+    for (int dens : {10, 35, 60, 90}) {
+        uint64_t hL[nwin], hT[nwin];
+        srand(1);
+        for (int w = 0; w < nwin; w++) {
+            uint64_t l = 0, t = 0;
+            for (int b = 0; b < 64; b++) {
+                if (rand() % 100 < 45) l |= 1ull << b;
+                if (rand() % 100 < dens) t |= 1ull << b;
             }
+            hL[w] = l; hT[w] = t;
+        }
+        CHK(hipMemcpy(dL, hL, sizeof(hL), hipMemcpyHostToDevice));
+        CHK(hipMemcpy(dT, hT, sizeof(hT), hipMemcpyHostToDevice));
+        printf("-- type-A density %d %%\n", dens);
+        run<0>("V0 current", dL, dT, nwin, 512, 256, 1, dout);
+        run<1>("V1 two hops per trip", dL, dT, nwin, 512, 256, 1, dout);
+        run<2>("V2 lean (no rel, T>>d+1)", dL, dT, nwin, 512, 256, 1, dout);
+        run<3>("V3 no readlane (lower bound)", dL, dT, nwin, 512, 256, 1, dout);
+    }
     return 0;
 }
