@@ -943,6 +943,12 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         blk0 = c0;
                     };
                     build_block(0);
+#ifdef DEC_PAD  // set by the Makefile (tools/hop_align.py): s_nop padding, run once per phase, that puts the hop loop
+                // below 16 bytes into a 32-byte fetch block (5 % between the best and the worst offset, measured)
+#define DEC_STR2(x) #x
+#define DEC_STR(x) DEC_STR2(x)
+                    asm volatile(".p2align 6\n\t.fill " DEC_STR(DEC_PAD) ", 4, 0xBF800000");
+#endif
                     while (i < sCur) {
                         if (sP >= sNb) {
                             if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Build helper (spiht_amd/csrc/Makefile): how many s_nop to put in front of the decoder's window loop so that the
+hand-written hop loop of k_decode<false> starts 16 bytes into a 32-byte block -- measured best on MI355X (decode of 256
+images: 8.53 ms at offset 16, 8.73 at 24, 8.83 at 0, 8.99 at 8).  Input: decode.hip compiled for the device only with
+-DDEC_PAD=0.  Prints the pad count (0 if anything goes wrong: the build then just keeps whatever alignment it has)."""
+import re
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/llvm/bin/"
+try:
+    obj = sys.argv[1]
+    elf = tempfile.mktemp(suffix=".elf", dir="/tmp")
+    subprocess.check_call([LLVM + "clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    dis = subprocess.check_output([LLVM + "llvm-objdump", "-d", elf], text=True)
+    # the hop loop is the only user of s_ff1_i32_b64 followed by s_add_i32 / two s_lshr_b64; k_decode<false> comes last
+    addrs = [int(m.group(1), 16) for m in re.finditer(r"s_ff1_i32_b64 .*// ([0-9A-Fa-f]+):", dis)]
+    label = addrs[-2]  # two bodies per loop: the first one of the last pair is the loop label
+    print(((16 - label) % 32) // 4)
+except Exception:
+    print(0)
