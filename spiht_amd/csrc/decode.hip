@@ -1123,15 +1123,26 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 
         // ---------------- scatter decoded values ----------------
         __syncthreads();
-        for (uint32_t t = cut + threadIdx.x; t < lsp_len; t += DEC_NW * 64) {
-            int32_t v = lsp_val[t];
-            if (v) out[lsp_idx[t] & IDXM] = v;
-        }
+        // four entries per thread per round, all loads before the stores: the stores may alias the lists as far as
+        // the compiler knows, so a plain loop would wait for memory once per entry
+        auto scatter = [&](uint32_t t_begin, uint32_t t_end) {
+            for (uint32_t t0 = t_begin + threadIdx.x; t0 < t_end; t0 += DEC_NW * 64 * 4) {
+                int32_t v[4];
+                uint32_t ix[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t0 + (uint32_t)u * DEC_NW * 64;
+                    v[u] = t < t_end ? lsp_val[t] : 0;
+                    ix[u] = t < t_end ? lsp_idx[t] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (v[u]) out[ix[u] & IDXM] = v[u];
+            }
+        };
+        scatter(cut, lsp_len);
         __syncthreads();
-        for (uint32_t t = threadIdx.x; t < cut; t += DEC_NW * 64) {
-            int32_t v = lsp_val[t];
-            if (v) out[lsp_idx[t] & IDXM] = v;
-        }
+        scatter(0, cut);
         __syncthreads();
         if (threadIdx.x == 0) {
             const uint32_t nt = sh.ntail < DEC_TAIL ? sh.ntail : DEC_TAIL;
