@@ -20,6 +20,7 @@ int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxab
 int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
+int spiht_launch_unscatter(const DecArgs *a, hipStream_t st);
 int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes);
 int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                           void *temp, size_t temp_bytes, hipStream_t st);
@@ -79,6 +80,9 @@ struct spiht_ctx {
     // grow-only scratch
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
+    // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
+    DevBuf recz, lspcnt;
+    bool recz_clean = false;
     // timing
     bool timing = false;
     struct Rec { int stage; hipEvent_t a, b; };
@@ -348,7 +352,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
-                      &ctx->img, &ctx->trace, &ctx->meta};
+                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -367,6 +371,7 @@ extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));
     int st = read_err(ctx);  // includes the stream synchronize
     if (st != SPIHT_OK) {
+        ctx->recz_clean = false;  // a guard tripped: the decoder's lists may not describe what it wrote
         (void)clear_err(ctx);
         (void)hipStreamSynchronize(ctx->stream);
     }
@@ -533,7 +538,7 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
 static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, uint64_t slot_stride,
                          const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out,
                          uint32_t *d_tr_ent = nullptr, uint8_t *d_tr_act = nullptr, uint64_t tr_stride = 0,
-                         bool zero_out = true) {
+                         bool zero_out = true, DecArgs *args_out = nullptr) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if (slot_stride * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
     ListCaps caps;
@@ -560,10 +565,15 @@ static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, u
     a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
     a.err = (uint32_t *)ctx->err.p;
     a.tr_ent = d_tr_ent; a.tr_act = d_tr_act; a.tr_stride = tr_stride;
+    if (args_out) {  // the caller wants to undo the scatter later: one LSP length per slot
+        CHK(ensure(ctx, ctx->lspcnt, (size_t)nslots * 4));
+        a.lsp_count = (uint32_t *)ctx->lspcnt.p;
+    }
     {
         StageTimer t(ctx, ST_DEC_LISTS);
         LAUNCHCHK(spiht_launch_decode(&a, ctx->stream));
     }
+    if (args_out) *args_out = a;
     return SPIHT_OK;
 }
 
@@ -1068,13 +1078,34 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         int32_t *rec = d_rec ? d_rec + (size_t)b0 * g.n : nullptr;
-        if (!rec) {
-            CHK(ensure(ctx, ctx->rec, (size_t)nb * g.n * 4));
-            rec = (int32_t *)ctx->rec.p;
+        if (rec) {
+            CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec));
+            CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
+                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+            continue;
         }
-        CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec));
+        // Internal coefficient array: it is all zero on entry and is left all zero -- after the inverse transform the
+        // cells the decoder wrote are cleared again through its own LSP lists (about 1 % of the array) instead of
+        // zero-filling 26 MB per 1080p image before every decode.
+        const void *old_p = ctx->recz.p;
+        CHK(ensure(ctx, ctx->recz, (size_t)nb * g.n * 4));
+        if (ctx->recz.p != old_p || !ctx->recz_clean) {
+            StageTimer t(ctx, ST_MEMSET);
+            HIPCHK(hipMemsetAsync(ctx->recz.p, 0, ctx->recz.cap, ctx->stream));
+            ctx->recz_clean = true;
+        }
+        rec = (int32_t *)ctx->recz.p;
+        DecArgs da;
+        CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec, nullptr,
+                          nullptr, 0, false, &da));
         CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
                         d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+        if (da.nslots >= nb) {
+            StageTimer t(ctx, ST_MEMSET);
+            LAUNCHCHK(spiht_launch_unscatter(&da, ctx->stream));
+        } else {
+            ctx->recz_clean = false;  // slots were reused inside the launch: the lists of earlier images are gone
+        }
     }
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }

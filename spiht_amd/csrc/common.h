@@ -87,6 +87,7 @@ struct DecArgs {
     uint32_t *lip0, *lip1, *lsp_idx, *lis0, *lis1, *lis2;
     int32_t *lsp_val;
     uint32_t *err;
+    uint32_t *lsp_count;      // [nslots] or null: final LSP length of the image a slot decoded (k_unscatter)
     // decode_with_metadata only (k_decode<true>): one trace record per stream position 0..nbits (the last one is
     // the operation that was waiting for a bit when the stream ended)
     uint32_t *tr_ent;         // [B, tr_stride]  entry: node index | filter << 28 (| ENT_A / ENT_LEAF, ignored)

@@ -1157,6 +1157,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 if (op.n & 0x80000000u) out[op.idx] = set_bit_i32(out[op.idx], op.n & 0xFFu, (uint32_t)op.val);
                 else out[op.idx] = op.val;
             }
+            if (a.lsp_count) a.lsp_count[slot] = lsp_len;
             uint32_t ecode = 0;
             if (bad) ecode |= 1u | 0x100u;
             if (sh.bad == 1) ecode |= 1u | 0x200u;            // list capacity
@@ -1170,6 +1171,24 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         }
         __syncthreads();
     }
+}
+
+// Puts back the zeros: clears exactly the cells the decoder wrote (its LSP lists are still in the slot scratch), so a
+// coefficient array that is only ever used as decoder output and inverse-transform input never needs a full zero-fill
+// again.  One image per slot (B <= nslots).
+#define UNSC_BLOCKS 8
+__global__ __launch_bounds__(256) void k_unscatter(DecArgs a) {
+    const uint32_t slot = blockIdx.x / UNSC_BLOCKS, part = blockIdx.x % UNSC_BLOCKS;
+    const uint32_t cnt = a.lsp_count[slot];
+    const uint32_t *idx = a.lsp_idx + (size_t)slot * a.caps.lsp;
+    int32_t *out = a.out + (size_t)slot * a.g.n;
+    for (uint32_t t = part * 256u + threadIdx.x; t < cnt; t += UNSC_BLOCKS * 256u) out[idx[t] & ENT_IDX] = 0;
+}
+
+extern "C" int spiht_launch_unscatter(const DecArgs *a, hipStream_t st) {
+    if (a->B < 1) return 0;
+    hipLaunchKernelGGL(k_unscatter, dim3(a->B * UNSC_BLOCKS), dim3(256), 0, st, *a);
+    return (int)hipGetLastError();
 }
 
 extern "C" int spiht_launch_decode(const DecArgs *a, hipStream_t st) {
