@@ -277,9 +277,10 @@ static void list_caps(const Geom &g, uint64_t max_bits, ListCaps *caps, uint64_t
         lsp = std::min(lsp, mb / 2 + 1);
         lis = std::min(lis, roots + 4 * mb);
     }
-    caps->lip = (uint32_t)std::min<uint64_t>(lip + 64, 0xFFFFFFF0ull);
-    caps->lsp = (uint32_t)std::min<uint64_t>(lsp + 64, 0xFFFFFFF0ull);
-    caps->lis = (uint32_t)std::min<uint64_t>(lis + 64, 0xFFFFFFF0ull);
+    // multiples of 64 entries: every slot's lists start 256-byte aligned (the encoder reads entry pairs as 8-byte loads)
+    caps->lip = (uint32_t)std::min<uint64_t>((lip + 127) & ~63ull, 0xFFFFFFC0ull);
+    caps->lsp = (uint32_t)std::min<uint64_t>((lsp + 127) & ~63ull, 0xFFFFFFC0ull);
+    caps->lis = (uint32_t)std::min<uint64_t>((lis + 127) & ~63ull, 0xFFFFFFC0ull);
     caps->pad = 0;
     if (nodes_out) *nodes_out = nodes;
 }

@@ -189,24 +189,36 @@ __global__ __launch_bounds__(BLOCK) void k_encode(EncArgs a) {
             const uint32_t lsp_len0 = lsp_len;
 
             // ---- LIP pass (encoder_decoder.rs:207-222) ----
+            // two consecutive entries per thread: half as many scans / barriers per entry (the pass is bound by those,
+            // not by its loads: 16 wavefronts per CU hide them)
             uint32_t lipn_len = 0;
-            for (uint32_t base = 0; base < lip_len && !done; base += BLOCK) {
-                uint32_t r = base + tid;
-                bool act = r < lip_len;
-                uint32_t e = act ? lip[r] : 0;
-                int32_t xv = act ? X[e] : 0;
-                bool sig = act && iabs_u(xv) >= T;
-                uint32_t bits = sig ? (1u | ((xv >= 0) ? 2u : 0u)) : 0u;
-                uint32_t nb = act ? (sig ? 2u : 1u) : 0u;
-                uint64_t pk = (uint64_t)nb | ((uint64_t)(sig ? 1u : 0u) << 16) | ((uint64_t)((act && !sig) ? 1u : 0u) << 32);
+            for (uint32_t base = 0; base < lip_len && !done; base += 2 * BLOCK) {
+                const uint32_t r = base + 2 * tid;
+                const bool act0 = r < lip_len, act1 = r + 1 < lip_len;
+                uint32_t e0 = 0, e1 = 0;
+                if (act1) {
+                    const uint2 ee = *reinterpret_cast<const uint2 *>(lip + r);  // r is even, the list is 256-byte aligned
+                    e0 = ee.x; e1 = ee.y;
+                } else if (act0) {
+                    e0 = lip[r];
+                }
+                const int32_t x0 = act0 ? X[e0] : 0, x1 = act1 ? X[e1] : 0;
+                const bool sig0 = act0 && iabs_u(x0) >= T, sig1 = act1 && iabs_u(x1) >= T;
+                const uint32_t b0 = sig0 ? (1u | ((x0 >= 0) ? 2u : 0u)) : 0u, b1 = sig1 ? (1u | ((x1 >= 0) ? 2u : 0u)) : 0u;
+                const uint32_t nb0 = act0 ? (sig0 ? 2u : 1u) : 0u, nb1 = act1 ? (sig1 ? 2u : 1u) : 0u;
+                const uint32_t ns = (sig0 ? 1u : 0u) + (sig1 ? 1u : 0u);
+                const uint32_t nn = ((act0 && !sig0) ? 1u : 0u) + ((act1 && !sig1) ? 1u : 0u);
+                uint64_t pk = (uint64_t)(nb0 + nb1) | ((uint64_t)ns << 16) | ((uint64_t)nn << 32);
                 uint64_t tot;
                 uint64_t ex = block_exscan<BLOCK>(pk, tot, sh, par);
                 par ^= 1;
                 uint32_t totLSP = (uint32_t)(tot >> 16) & 0xffffu;
                 if (lsp_len + totLSP > a.caps.lsp) { bad = true; done = true; break; }
-                if (sig) lsp[lsp_len + ((uint32_t)(ex >> 16) & 0xffffu)] = e;
-                else if (act) lipn[lipn_len + (uint32_t)(ex >> 32)] = e;
-                emit_bits<BLOCK>(bits, nb, (uint32_t)ex & 0xffffu, (uint32_t)tot & 0xffffu, bitpos, max_bits, outw, sh, wpar);
+                uint32_t os = lsp_len + ((uint32_t)(ex >> 16) & 0xffffu), ol = lipn_len + (uint32_t)(ex >> 32);
+                if (sig0) lsp[os++] = e0; else if (act0) lipn[ol++] = e0;
+                if (sig1) lsp[os] = e1; else if (act1) lipn[ol] = e1;
+                emit_bits<BLOCK>(b0 | (b1 << nb0), nb0 + nb1, (uint32_t)ex & 0xffffu, (uint32_t)tot & 0xffffu, bitpos, max_bits, outw,
+                                 sh, wpar);
                 wpar ^= 1;
                 lsp_len += totLSP;
                 lipn_len += (uint32_t)(tot >> 32);
@@ -307,13 +319,20 @@ __global__ __launch_bounds__(BLOCK) void k_encode(EncArgs a) {
             qa = cur; qb = nxt;
 
             // ---- refinement (encoder_decoder.rs:286-292) ----
-            for (uint32_t base = 0; base < lsp_len0 && !done; base += BLOCK) {
-                uint32_t r = base + tid;
-                bool act = r < lsp_len0;
-                uint32_t e = act ? lsp[r] : 0;
-                uint32_t bit = act ? ((iabs_u(X[e]) >> n) & 1u) : 0u;
-                uint32_t cnt = (lsp_len0 - base) < (uint32_t)BLOCK ? (lsp_len0 - base) : (uint32_t)BLOCK;
-                emit_bits<BLOCK>(bit, act ? 1u : 0u, tid, cnt, bitpos, max_bits, outw, sh, wpar);
+            for (uint32_t base = 0; base < lsp_len0 && !done; base += 2 * BLOCK) {  // two entries per thread, as above
+                const uint32_t r = base + 2 * tid;
+                const bool act0 = r < lsp_len0, act1 = r + 1 < lsp_len0;
+                uint32_t e0 = 0, e1 = 0;
+                if (act1) {
+                    const uint2 ee = *reinterpret_cast<const uint2 *>(lsp + r);
+                    e0 = ee.x; e1 = ee.y;
+                } else if (act0) {
+                    e0 = lsp[r];
+                }
+                const uint32_t bit0 = act0 ? ((iabs_u(X[e0]) >> n) & 1u) : 0u, bit1 = act1 ? ((iabs_u(X[e1]) >> n) & 1u) : 0u;
+                const uint32_t cnt = (lsp_len0 - base) < 2u * BLOCK ? (lsp_len0 - base) : 2u * BLOCK;
+                emit_bits<BLOCK>(bit0 | (bit1 << 1), (act0 ? 1u : 0u) + (act1 ? 1u : 0u), 2 * tid, cnt, bitpos, max_bits, outw, sh,
+                                 wpar);
                 wpar ^= 1;
                 if (bitpos >= max_bits) done = true;
             }
