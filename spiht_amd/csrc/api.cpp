@@ -1250,6 +1250,16 @@ extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, in
 }
 
 // diagnostic: copy the device error/debug words (64 x uint32) to the host
+extern "C" int spiht_launch_spin(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, hipStream_t st);
+// diagnostic, not part of the ABI header: occupy the GPU with `blocks` idle workgroups for `ticks` clock ticks
+extern "C" int spiht_debug_spin(spiht_ctx *ctx, int blocks, int threads, uint64_t ticks, uint32_t lds_bytes) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    LAUNCHCHK(spiht_launch_spin(blocks, threads, ticks, lds_bytes, (uint32_t *)ctx->err.p + 8, ctx->stream));
+    return SPIHT_OK;
+}
+
 extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
     if (!ctx || !out64) return SPIHT_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));

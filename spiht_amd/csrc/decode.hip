@@ -97,17 +97,25 @@ struct LipItem {  // one LIP-pass window, produced by the parallel window scan
 };
 
 struct DecShared {
-    LipItem lipq[DEC_NW * 64];
+    // The LIP pass and the LIS pass never run at the same time (barriers between them), so their scratch shares
+    // memory: 17 KB instead of 25 KB per workgroup.  That matters when this kernel runs next to the DWT kernels on
+    // another stream: 4 of their workgroups (34 KB each) + one of ours fit a CU's 160 KB, 4 + a 25 KB one do not
+    // (tools/corun_spin.py: the DWT is 23 % slower next to idle 25 KB workgroups, not at all next to 0 KB ones).
+    union {
+        LipItem lipq[DEC_NW * 64];
+        struct {
+            Slot ring[DEC_RING];
+            Chain chain[DEC_RING];
+            PhaseInfo ph;
+            // helper -> sequencer: per window, the stream bits and, per window position, the length a fired type-A
+            // entry would have if it started there
+            uint64_t plo[DEC_PREP];
+            uint8_t plav[DEC_PREP][64];
+        };
+    };
     uint64_t wpart[DEC_NW];     // per-wave partials of the block scans
     uint32_t wfun[DEC_NW];      // per-wave carry functions
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
-    Slot ring[DEC_RING];
-    Chain chain[DEC_RING];
-    PhaseInfo ph;
-    // helper -> sequencer: per window, the stream bits and, per window position, the length a fired type-A entry
-    // would have if it started there
-    uint64_t plo[DEC_PREP];
-    uint8_t plav[DEC_PREP][64];
     uint32_t pprog;             // windows of this phase the helper has prepared
     uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_PREP_B)
     uint32_t head;              // items produced so far
@@ -889,6 +897,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 lip_len = lipn_len;
                 if (dn) done = true;
                 { uint32_t *t = lip; lip = lipn; lipn = t; }
+                // the LIP scratch overlays the LIS ring: its flags have to start from "nothing published" again (the
+                // barrier that ends every round above has already put all waves past their last read of lipq)
+                if (threadIdx.x < DEC_RING) { sh.ring[threadIdx.x].ready = 0; sh.chain[threadIdx.x].seq = 0; }
                 __syncthreads();
                 PF_ADD(0);
             }

@@ -310,7 +310,9 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // ------------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------------
-#define IW_TH 32    // output rows per tile (two halves of 16, one per half of the workgroup)
+#define IW_TH 32    // output rows per tile (two halves of 16, one per half of the workgroup; a multiple of 4).  28 rows
+                    // (34 KB of LDS instead of 38, so that four tiles fit a CU next to a list-coder workgroup of another
+                    // stream) was tried: 3 % slower alone and no faster when overlapped
 #define IW_TW 128   // output cols per tile, one thread per column per half
 
 __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {

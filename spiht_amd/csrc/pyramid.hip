@@ -218,3 +218,20 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
     hipLaunchKernelGGL(k_pyr_ll, grid, dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
+
+// diagnostic (tools/corun.py): workgroups that occupy the CUs for a given number of clock ticks without touching memory
+__global__ __launch_bounds__(512) void k_spin(uint64_t ticks, uint32_t lds_words, uint32_t *sink) {
+    extern __shared__ uint32_t dyn[];
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t acc = 0;
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        acc++;
+    }
+    if (lds_words) dyn[threadIdx.x % lds_words] = acc;
+    if (acc == 0xFFFFFFFFu) *sink = acc;
+}
+extern "C" int spiht_launch_spin(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, hipStream_t st) {
+    hipLaunchKernelGGL(k_spin, dim3(blocks), dim3(threads), lds_bytes, st, ticks, lds_bytes / 4, sink);
+    return (int)hipGetLastError();
+}

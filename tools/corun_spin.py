@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Diagnostic: does the forward / inverse DWT slow down merely because another kernel's workgroups are RESIDENT on the
+CUs (no memory traffic at all)?  python tools/corun_spin.py [batch]"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spiht_amd import _lib
+from spiht_amd.batch import BatchCodec, DeviceArray
+from spiht_amd.spiht_wrapper import SpihtSettings
+from bench import synth_image, H, W, C_IMG, LEVEL, BPP
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ctx = _lib.default_context(0)
+ctx2 = _lib.Context(0)
+L = _lib.lib()
+L.spiht_debug_spin.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint32]
+codec = BatchCodec(C_IMG, H, W, SpihtSettings(), LEVEL, int(H * W * BPP), ctx=ctx)
+g = codec.geom
+n = C_IMG * g["enc_h"] * g["enc_w"]
+img = synth_image(1000, C_IMG, H, W)
+d_img = DeviceArray(ctx, (B, C_IMG, H, W), np.float64)
+for b in range(B):
+    d_img.upload(img, offset_bytes=b * C_IMG * H * W * 8)
+d_coef = DeviceArray(ctx, (B, n), np.int32)
+d_img2 = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
+vp = C.c_void_p
+
+
+def dwt():
+    _lib.check(L.spiht_dwt_quant_batch_f64(ctx2.handle, vp(d_img.ptr), B, C_IMG, H, W, codec.wid, codec.mid, LEVEL, 50.0, None,
+                                           vp(d_coef.ptr)))
+
+
+def idwt():
+    _lib.check(L.spiht_dequant_idwt_batch_f64(ctx2.handle, vp(d_coef.ptr), B, C_IMG, H, W, codec.wid, codec.mid, LEVEL, 50.0, None,
+                                              vp(d_img2.ptr)))
+
+
+def timed(fn, spin):
+    ctx.synchronize(); ctx2.synchronize()
+    ctx2.reset_timing(); ctx2.set_timing(True)
+    if spin:
+        blocks, threads, lds = spin
+        _lib.check(L.spiht_debug_spin(ctx.handle, blocks, threads, 100_000_000, lds))  # ~40 ms at 2.4 GHz... by s_memtime
+    fn(); fn()
+    ctx2.synchronize()
+    ctx2.set_timing(False)
+    t = sum(ms for k, (ms, c) in ctx2.timing().items() if c) / 2
+    ctx.synchronize()
+    return t
+
+
+dwt(); idwt(); ctx2.synchronize()
+for name, fn in (("dwt", dwt), ("idwt", idwt)):
+    base = timed(fn, None)
+    print("%-5s alone %.2f ms" % (name, base))
+    for spin in ((256, 512, 0), (256, 512, 16832), (256, 512, 20480), (256, 512, 24784), (256, 64, 0), (512, 512, 16832)):
+        t = timed(fn, spin)
+        print("   with %4d idle workgroups of %4d threads, %5d B LDS: %.2f ms (x%.2f)" % (spin[0], spin[1], spin[2], t, t / base))
