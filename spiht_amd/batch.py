@@ -134,6 +134,14 @@ class BatchCodec:
             for d in (d_data, d_nbytes, d_maxn, d_img):
                 d.free()
 
+    def decode_prefixes(self, result, byte_lengths):
+        """Progressive decoding (the pattern of the reference's make_gif.py:46-61): decode the
+        prefixes `result.encoded_bytes[:k]` for every k in byte_lengths in ONE batch -> float64 [K,c,H',W'].
+        Any prefix of a SPIHT stream is a valid stream; every image of the batch is decoded by its own workgroup."""
+        pre = [EncodingResult(result.encoded_bytes[:int(k)], result.h, result.w, result.c, result.max_n, result.level)
+               for k in byte_lengths]
+        return self.decode(pre)
+
 
 class OverlappedCodec:
     """Round trips a sequence of batches with the two kinds of work on two contexts.

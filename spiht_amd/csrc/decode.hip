@@ -1008,7 +1008,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             // mask from the current entry on, so a candidate is `L & T` (s_and sets SCC), its offset
                             // d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (two shifts each: a single shift count
                             // must stay below 64).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and, about 100
-                            // cycles (tools/ubench/hop.hip); two hops per trip save the taken branch every other hop.
+                            // cycles (tools/ubench/hop.hip); four hops per trip save three of four taken branches.
                             // Four SALU instructions separate the s_add that makes the lane select from v_readlane.
 #define HOP_BODY                                                \
     "s_ff1_i32_b64 %[d], %[c]\n\t"                              \
@@ -1027,6 +1027,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                                 "s_and_b64 %[c], %[L], %[T]\n\t"
                                 "s_cbranch_scc0 s_hop_done%=\n"
                                 "s_hop_loop%=:\n\t"
+                                HOP_BODY
+                                "s_cbranch_scc0 s_hop_done%=\n\t"
+                                HOP_BODY
+                                "s_cbranch_scc0 s_hop_done%=\n\t"
                                 HOP_BODY
                                 "s_cbranch_scc0 s_hop_done%=\n\t"
                                 HOP_BODY

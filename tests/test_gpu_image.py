@@ -278,3 +278,22 @@ def test_overlapped_codec_matches_fused(oracle):
         rec = d_recs[s].download()
         ref = np.stack(codec.decode(res))
         assert np.array_equal(rec[:, :, :ref.shape[2], :ref.shape[3]], ref)
+
+
+def test_progressive_prefixes_in_one_batch(oracle):
+    """make_gif.py:46-61: byte prefixes of one stream, decoded together; quality never gets worse"""
+    import spiht_amd
+    from spiht_amd.batch import BatchCodec
+    c, H, W = 3, 120, 168
+    img = synth_image(77, c, H, W)
+    s = spiht_amd.SpihtSettings()
+    codec = BatchCodec(c, H, W, s, None, None)
+    res = codec.encode(img[None])[0]
+    ks = [0, 1, 50, 400, 3000, len(res.encoded_bytes) // 2, len(res.encoded_bytes)]
+    ims = codec.decode_prefixes(res, ks)
+    errs = []
+    for k, im in zip(ks, ims):
+        one = spiht_amd.decode_image(spiht_amd.EncodingResult(res.encoded_bytes[:k], H, W, c, res.max_n, None), s)
+        assert np.array_equal(im[:, :H, :W], one)
+        errs.append(float(np.abs(one - img).mean()))
+    assert errs[-1] < errs[3] < errs[0] and errs[-1] < 0.01

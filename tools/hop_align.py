@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Build helper (spiht_amd/csrc/Makefile): how many s_nop to put in front of the decoder's window loop so that the
-hand-written hop loop of k_decode<false> starts 16 bytes into a 32-byte block -- measured best on MI355X (decode of 256
-images: 8.53 ms at offset 16, 8.73 at 24, 8.83 at 0, 8.99 at 8).  Input: decode.hip compiled for the device only with
+hand-written hop loop of k_decode<false> starts 20 bytes into a 32-byte block -- measured best on MI355X (decode of 256
+images, four hops per loop trip: 8.39 ms at offset 20, 8.46 at 12, 8.65 at 8; with two hops per trip the spread was
+8.53 ... 8.99 ms).  Input: decode.hip compiled for the device only with
 -DDEC_PAD=0.  Prints the pad count (0 if anything goes wrong: the build then just keeps whatever alignment it has)."""
 import re
 import subprocess
@@ -18,7 +19,8 @@ try:
     dis = subprocess.check_output([LLVM + "llvm-objdump", "-d", elf], text=True)
     # the hop loop is the only user of s_ff1_i32_b64 followed by s_add_i32 / two s_lshr_b64; k_decode<false> comes last
     addrs = [int(m.group(1), 16) for m in re.finditer(r"s_ff1_i32_b64 .*// ([0-9A-Fa-f]+):", dis)]
-    label = addrs[-2]  # two bodies per loop: the first one of the last pair is the loop label
-    print(((16 - label) % 32) // 4)
+    BODIES = 4         # hop bodies per loop trip (decode.hip)
+    label = addrs[-BODIES]  # the first one of the last group is the loop label
+    print(((20 - label) % 32) // 4)
 except Exception:
     print(0)
