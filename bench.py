@@ -51,7 +51,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="images the CPU baseline codes (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24,
+                    help="images the CPU baseline codes, cycling through the distinct ones (0 = skip); 24 = about 11 s of one core")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: steps are software-pipelined over two contexts -- the HBM-bound halves (DWT + pyramid of step "
                          "i+1, inverse DWT of step i-1) run while the list coder works on step i "
@@ -301,11 +302,11 @@ def main():
         # ---- CPU baseline: the oracle (port of the reference algorithm) on a bounded sample, one core ----
         if args.cpu_sample > 0:
             from oracle import oracle as O
-            ns = min(args.cpu_sample, nd)
+            ns = args.cpu_sample
             tc = time.perf_counter()
             streams = []
             for i in range(ns):
-                data, mn, _ = O.encode_image(base[i], WAVELET, MODE, LEVEL, QSCALE, None, max_bits)
+                data, mn, _ = O.encode_image(base[i % nd], WAVELET, MODE, LEVEL, QSCALE, None, max_bits)
                 streams.append((data, mn))
             t_enc = time.perf_counter() - tc
             tc = time.perf_counter()
