@@ -57,8 +57,8 @@ def main():
                     help="1: steps are software-pipelined over two contexts -- the HBM-bound halves (DWT + pyramid of step "
                          "i+1, inverse DWT of step i-1) run while the list coder works on step i "
                          "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  Measured: "
-                         "25.3 vs 30.0 ms/step (+19 %% images/s), but co-running kernels slow each other (list decoder "
-                         "x1.5-1.8, DWT x1.4: tools/corun.py), so the DWT's own roofline fraction drops from 0.58 to 0.42.  "
+                         "22.2 vs 24.5 ms/step (+10 %% images/s), but co-running kernels slow each other (list decoder "
+                         "x1.5-1.8, DWT x1.4: tools/corun.py), so the DWT's own roofline fraction drops from 0.62 to 0.54.  "
                          "0 (default): every step runs its stages back to back on one stream, each kernel with the whole GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
