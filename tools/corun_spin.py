@@ -40,24 +40,32 @@ def idwt():
                                               vp(d_img2.ptr)))
 
 
-def timed(fn, spin):
+def timed_once(fn, spin):
     ctx.synchronize(); ctx2.synchronize()
     ctx2.reset_timing(); ctx2.set_timing(True)
     if spin:
         blocks, threads, lds = spin
-        _lib.check(L.spiht_debug_spin(ctx.handle, blocks, threads, 100_000_000, lds))  # ~40 ms at 2.4 GHz... by s_memtime
-    fn(); fn()
+        _lib.check(L.spiht_debug_spin(ctx.handle, blocks, threads, 40_000_000, lds))  # outlasts the transform
+    fn()
     ctx2.synchronize()
     ctx2.set_timing(False)
-    t = sum(ms for k, (ms, c) in ctx2.timing().items() if c) / 2
+    t = sum(ms for k, (ms, c) in ctx2.timing().items() if c)
     ctx.synchronize()
     return t
 
 
+def timed(fn, spin, reps=7):
+    ts = sorted(timed_once(fn, spin) for _ in range(reps))
+    return ts[0], ts[len(ts) // 2]
+
+
 dwt(); idwt(); ctx2.synchronize()
+CONFIGS = ((256, 512, 0), (256, 512, 8192), (256, 512, 16832), (256, 512, 24784), (256, 512, 40000), (256, 64, 0), (256, 64, 16832),
+           (512, 512, 16832))
 for name, fn in (("dwt", dwt), ("idwt", idwt)):
-    base = timed(fn, None)
-    print("%-5s alone %.2f ms" % (name, base))
-    for spin in ((256, 512, 0), (256, 512, 16832), (256, 512, 20480), (256, 512, 24784), (256, 64, 0), (512, 512, 16832)):
-        t = timed(fn, spin)
-        print("   with %4d idle workgroups of %4d threads, %5d B LDS: %.2f ms (x%.2f)" % (spin[0], spin[1], spin[2], t, t / base))
+    bmin, bmed = timed(fn, None)
+    print("%-5s alone: min %.2f  median %.2f ms" % (name, bmin, bmed))
+    for spin in CONFIGS:
+        tmin, tmed = timed(fn, spin)
+        print("   with %4d idle workgroups of %4d threads, %5d B LDS: min %.2f (x%.2f)  median %.2f (x%.2f)"
+              % (spin[0], spin[1], spin[2], tmin, tmin / bmin, tmed, tmed / bmed))
