@@ -209,5 +209,27 @@ def part_wrapper():
     print("wrote wrapper_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
 
 
+def part_bench():
+    """Digests of what the reference wrapper hands to its Rust core (spiht_wrapper.py:163-172, PyWavelets) for the
+    eight 1080p images of bench.py and a few odd-sized uint8-derived ones: on such pixels the products coefficient x q
+    often land exactly on integers, so the quantised array is sensitive to the last bit of the transform."""
+    import hashlib
+    import pywt
+    cases = [(1000 + i, 3, 1080, 1920, "bior2.2", 7, 50.0) for i in range(8)]
+    cases += [(5, 3, 511, 733, "bior2.2", None, 50.0), (6, 1, 512, 512, "bior4.4", 5, 50.0), (7, 3, 300, 301, "bior6.8", 3, 50.0),
+              (8, 3, 257, 255, "bior2.2", 4, 10.0)]
+    out = {"cases": np.array([[s, c, h, w, -1 if lv is None else lv] for s, c, h, w, _, lv, _ in cases]),
+           "wavelets": np.array([wv for _, _, _, _, wv, _, _ in cases]), "q": np.array([q for *_, q in cases])}
+    dig = []
+    for seed, c, h, w, wv, lv, q in cases:
+        img = synth_image(seed, c, h, w)
+        arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wv, level=lv, mode="reflect"), axes=(-2, -1))
+        qa = np.ascontiguousarray((arr * q).astype(np.int32))
+        dig.append(hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape)
+    out["sha1"] = np.array(dig)
+    np.savez_compressed(os.path.join(HERE, "bench_pywt_digests.npz"), **out)
+    print("wrote bench_pywt_digests.npz:", len(cases), "cases; pywt", pywt.__version__)
+
+
 if __name__ == "__main__":
-    {"loops": part_loops, "wrapper": part_wrapper}[sys.argv[1]]()
+    {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench}[sys.argv[1]]()

@@ -118,3 +118,31 @@ def test_forward_inverse_vs_oracle(oracle, cfg):
         assert np.array_equal(back[b], ref), (cfg, float(np.abs(back[b] - ref).max()))
         # quantisation error only: the reconstruction is close to the input
         assert np.abs(back[b][:, :H, :W] - imgs[b]).max() < 0.2
+
+
+def test_quantised_transform_of_bench_images_matches_pywt_digests():
+    """the same digests as tests/test_oracle.py, from the GPU transform (through the C ABI): what bench.py codes is what
+    the reference's PyWavelets front end would hand to its Rust core"""
+    import ctypes as C
+    import hashlib
+    import os
+    from conftest import synth_image
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bench_pywt_digests.npz"))
+    ctx, L = _lib.default_context(), _lib.lib()
+    for row, wv, q, dig in zip(z["cases"], z["wavelets"], z["q"], z["sha1"]):
+        seed, c, h, w, lv = [int(v) for v in row]
+        wid = L.spiht_wavelet_id(str(wv).encode())
+        lvl, v = C.c_int(), [C.c_int64() for _ in range(6)]
+        _lib.check(L.spiht_geometry(h, w, wid, lv, C.byref(lvl), *[C.byref(t) for t in v]))
+        enc_h, enc_w = v[2].value, v[3].value
+        d_img = DeviceArray(ctx, (c, h, w), np.float64)
+        d_co = DeviceArray(ctx, (c, enc_h, enc_w), np.int32)
+        d_img.upload(synth_image(seed, c, h, w))
+        _lib.check(L.spiht_dwt_quant_batch_f64(ctx.handle, C.c_void_p(d_img.ptr), 1, c, h, w, wid, 0, lv, float(q), None,
+                                               C.c_void_p(d_co.ptr)))
+        ctx.synchronize()
+        qa = d_co.download()
+        assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == str(dig), (seed, h, w, str(wv))
+        d_img.free(); d_co.free()

@@ -212,3 +212,22 @@ def test_decode_with_metadata_restatement(oracle):
     assert meta.shape == (25, 8) and meta[24].any()
     with pytest.raises(oracle.OraclePanic):
         oracle.decode_with_metadata(data, n, c, h, w, 2, 2, top, other[:1])  # tree deeper than `level` (:603)
+
+
+def _bench_digest_cases():
+    z = np.load(os.path.join(GOLD, "bench_pywt_digests.npz"))
+    for row, wv, q, dig in zip(z["cases"], z["wavelets"], z["q"], z["sha1"]):
+        seed, c, h, w, lv = [int(v) for v in row]
+        yield seed, c, h, w, str(wv), (None if lv < 0 else lv), float(q), str(dig)
+
+
+def test_quantised_transform_of_bench_images_matches_pywt(oracle):
+    """tests/golden/bench_pywt_digests.npz (PyWavelets 1.1.1 through the reference wrapper's arithmetic): the int32
+    arrays the reference hands to its Rust core for bench.py's eight 1080p images and four odd-sized ones"""
+    import hashlib
+    from conftest import synth_image
+    for seed, c, h, w, wv, lv, q, dig in _bench_digest_cases():
+        arr = oracle.wavedec2_array(synth_image(seed, c, h, w), wv, "reflect", lv)
+        arr = arr[0] if isinstance(arr, tuple) else arr
+        qa = np.ascontiguousarray(oracle.quantize(arr, q))
+        assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == dig, (seed, h, w, wv)
