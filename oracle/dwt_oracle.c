@@ -330,3 +330,101 @@ int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int w
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-precision forward path.  PyWavelets transforms float32 (and float16) input in float32
+ * (_check_dtype), with float copies of the filters, and the wrapper then quantises the float32 array
+ * (spiht_wrapper.py:163-172 with :9-11; `arr * q_scale` stays float32, numpy scalar rules) -- unless
+ * per-channel scales are given: `channel_mults[:,None,None] * coeffs_arr` is float64 from there on.
+ *
+ * In float32 the ORDER of the additions matters for the quantised result, so this restates the order of
+ * pywt's convolution.template.c (downsampling_convolution, input at least as long as the filter): for
+ * outputs that do not hang over the right end, taps in ascending order; for the right overhang (i >= N),
+ * first the taps that read the extension, nearest first (filter index i-N down to 0), then the others
+ * ascending.  Checked against pywt 1.1.1: bit-identical float32 lines (tests/golden: wrapper32).
+ * ------------------------------------------------------------------------------------------------ */
+static void dwt_line_f(const float *x, int64_t N, int64_t sx, const float *lo, const float *hi, int F, int mode,
+                       float *ca, float *cd, int64_t so) {
+    int64_t L = (N + F - 1) / 2;
+    for (int64_t o = 0; o < L; o++) {
+        volatile float a = 0.0f, d = 0.0f; /* volatile: no contraction, no reassociation, no excess precision */
+        int64_t i = 2 * o + 1, jb = i >= N ? i - N : -1;
+        for (int s = 0; s < F; s++) {
+            int j = s <= jb ? (int)(jb - s) : s;
+            int64_t idx = ext_index(i - j, N, mode);
+            float v = idx < 0 ? 0.0f : x[idx * sx];
+            volatile float pa = lo[j] * v, pd = hi[j] * v;
+            a = a + pa;
+            d = d + pd;
+        }
+        ca[o * so] = a;
+        cd[o * so] = d;
+    }
+}
+
+/* float32 wavedec2 + coeffs_to_array; arr [c,enc_h,enc_w] float, zero padded.  Returns -3 when a level's input is
+ * shorter than the filter (pywt then runs a different loop whose order is not restated here). */
+int orc_wavedec2_array_f32(const float *img, int64_t c, int64_t H, int64_t W, int wid, int mode, int level, float *arr) {
+    if (wid < 0 || wid >= NWAVELETS) return -1;
+    const wavelet_t *wv = &WAVELETS[wid];
+    int F = wv->F;
+    int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
+    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    for (int l = 1; l <= L; l++)
+        if (hs[l - 1] < F || ws[l - 1] < F) return -3;
+    float lo[32], hi[32];
+    for (int j = 0; j < F; j++) { lo[j] = (float)wv->dec_lo[j]; hi[j] = (float)wv->dec_hi[j]; }
+    memset(arr, 0, sizeof(float) * c * eh * ew);
+    int64_t offh[64], offw[64];
+    int64_t ah = ll_h, aw = ll_w;
+    for (int l = L; l >= 1; l--) { offh[l] = ah; offw[l] = aw; ah += hs[l]; aw += ws[l]; }
+    for (int64_t k = 0; k < c; k++) {
+        float *cur = (float *)malloc(sizeof(float) * H * W);
+        if (!cur) return -2;
+        memcpy(cur, img + k * H * W, sizeof(float) * H * W);
+        float *out = arr + k * eh * ew;
+        for (int l = 1; l <= L; l++) {
+            int64_t h = hs[l - 1], w = ws[l - 1], h2 = hs[l], w2 = ws[l];
+            float *ta = (float *)malloc(sizeof(float) * h2 * w * 2), *aa = (float *)malloc(sizeof(float) * h2 * w2 * 4);
+            if (!ta || !aa) { free(ta); free(aa); free(cur); return -2; }
+            float *td = ta + h2 * w, *ad = aa + h2 * w2, *da = ad + h2 * w2, *dd = da + h2 * w2;
+            for (int64_t j = 0; j < w; j++) dwt_line_f(cur + j, h, w, lo, hi, F, mode, ta + j, td + j, w);  /* axis -2 */
+            for (int64_t i = 0; i < h2; i++) {                                                                 /* axis -1 */
+                dwt_line_f(ta + i * w, w, 1, lo, hi, F, mode, aa + i * w2, ad + i * w2, 1);
+                dwt_line_f(td + i * w, w, 1, lo, hi, F, mode, da + i * w2, dd + i * w2, 1);
+            }
+            for (int64_t i = 0; i < h2; i++)
+                for (int64_t j = 0; j < w2; j++) {
+                    out[i * ew + offw[l] + j] = ad[i * w2 + j];
+                    out[(offh[l] + i) * ew + j] = da[i * w2 + j];
+                    out[(offh[l] + i) * ew + offw[l] + j] = dd[i * w2 + j];
+                }
+            free(cur);
+            cur = (float *)malloc(sizeof(float) * h2 * w2);
+            if (!cur) { free(ta); free(aa); return -2; }
+            memcpy(cur, aa, sizeof(float) * h2 * w2);
+            free(ta); free(aa);
+        }
+        for (int64_t i = 0; i < ll_h; i++)
+            for (int64_t j = 0; j < ll_w; j++) out[i * ew + j] = cur[i * ws[L] + j];
+        free(cur);
+    }
+    return 0;
+}
+
+/* wrapper:167-172 on a float32 array: without channel scales the product with q_scale is float32 (numpy keeps the
+ * array's dtype against a Python scalar); with them the array is promoted to float64 first */
+void orc_quantize_f32(const float *arr, int64_t c, int64_t n_per_c, const double *mults /* or NULL */, double q, int32_t *out) {
+    const float qf = (float)q;
+    for (int64_t k = 0; k < c; k++)
+        for (int64_t t = 0; t < n_per_c; t++) {
+            if (mults) {
+                double v = mults[k] * (double)arr[k * n_per_c + t];
+                v = v * q;
+                out[k * n_per_c + t] = (int32_t)v;
+            } else {
+                volatile float v = arr[k * n_per_c + t] * qf;
+                out[k * n_per_c + t] = (int32_t)v;
+            }
+        }
+}

@@ -241,6 +241,34 @@ def wavedec2_array(img, wavelet, mode, level):
     return arr, g
 
 
+def wavedec2_array_f32(img, wavelet, mode, level):
+    """the float32 transform PyWavelets runs on float32 / float16 input -> float32 [c,enc_h,enc_w]"""
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    c, H, W = img.shape
+    g = geometry(H, W, wavelet, level)
+    arr = np.empty((c, g["enc_h"], g["enc_w"]), dtype=np.float32)
+    L = lib()
+    L.orc_wavedec2_array_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    rc = L.orc_wavedec2_array_f32(img.ctypes.data, c, H, W, wavelet_id(wavelet), MODES[mode],
+                                  -1 if level is None else int(level), arr.ctypes.data)
+    if rc:
+        raise RuntimeError("orc_wavedec2_array_f32 rc=%d" % rc)
+    return arr, g
+
+
+def quantize_f32(arr, q, mults=None):
+    """wrapper:167-172 on the float32 array (float32 product without channel scales, float64 with them)"""
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    c = arr.shape[0]
+    out = np.empty(arr.shape, dtype=np.int32)
+    m = None if mults is None else np.ascontiguousarray(mults, dtype=np.float64)
+    L = lib()
+    L.orc_quantize_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_double, C.c_void_p]
+    L.orc_quantize_f32.restype = None
+    L.orc_quantize_f32(arr.ctypes.data, c, arr.size // c, None if m is None else m.ctypes.data, float(q), out.ctypes.data)
+    return out
+
+
 def quantize(arr, q, mults=None):
     arr = np.ascontiguousarray(arr, dtype=np.float64)
     c = arr.shape[0]
@@ -281,8 +309,12 @@ def encode_image(image, wavelet="bior2.2", mode="reflect", level=None, q=50.0, m
                  rule=RULE_RUST):
     """CPU restatement of spiht_wrapper.encode_image (wrapper:142-189), no colour conversion.
     -> (bytes, max_n, geometry)"""
-    arr, g = wavedec2_array(image, wavelet, mode, level)
-    coeffs = quantize(arr, q, mults)
+    if np.asarray(image).dtype in (np.float32, np.float16):  # PyWavelets' single-precision path (_check_dtype)
+        arr, g = wavedec2_array_f32(image, wavelet, mode, level)
+        coeffs = quantize_f32(arr, q, mults)
+    else:
+        arr, g = wavedec2_array(image, wavelet, mode, level)
+        coeffs = quantize(arr, q, mults)
     mb = 99999999999999999 if max_bits is None else max_bits
     data, max_n = encode(coeffs, g["ll_h"], g["ll_w"], mb, rule)
     return data, max_n, g

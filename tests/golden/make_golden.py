@@ -231,5 +231,38 @@ def part_bench():
     print("wrote bench_pywt_digests.npz:", len(cases), "cases; pywt", pywt.__version__)
 
 
+def part_wrapper32():
+    """float32 pixels: PyWavelets transforms them in single precision and the wrapper quantises in single precision
+    (double once per-channel scales are applied).  Full float32 coefficient arrays for two small images, digests of
+    the int32 arrays handed to the Rust core for more and larger ones."""
+    import hashlib
+    import pywt
+    cases = [(21, 3, 64, 80, "bior2.2", 3, 50.0, None), (22, 1, 57, 43, "bior4.4", 2, 10.0, None),
+             (23, 3, 96, 128, "bior2.2", None, 50.0, [50.0, 15.0, 15.0]), (24, 3, 511, 733, "bior2.2", None, 50.0, None),
+             (1000, 3, 1080, 1920, "bior2.2", 7, 50.0, None), (25, 1, 300, 301, "bior6.8", 3, 33.3, None),
+             (26, 3, 257, 255, "bior2.2", 4, 0.1, None)]
+    out = {"ncases": np.array(len(cases))}
+    for i, (seed, c, h, w, wv, lv, q, mults) in enumerate(cases):
+        img = synth_image(seed, c, h, w).astype(np.float32 if i != 1 else np.float16)
+        arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wavelet=wv, level=lv, mode="reflect"), axes=(-2, -1))
+        assert arr.dtype == np.float32
+        a2 = arr
+        if mults is not None:
+            a2 = np.array(mults)[:, None, None] * a2
+        qa = np.ascontiguousarray((a2 * q).astype(np.int32))
+        p = "c%d_" % i
+        out[p + "meta"] = np.array([seed, c, h, w, -1 if lv is None else lv])
+        out[p + "wavelet"] = np.array(wv)
+        out[p + "q"] = np.array(q)
+        out[p + "mults"] = np.array(mults if mults else [], dtype=np.float64)
+        out[p + "f16"] = np.array(i == 1)
+        out[p + "sha1"] = np.array(hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape)
+        if h * w < 20000:
+            out[p + "arr"] = arr
+            out[p + "quant"] = qa
+    np.savez_compressed(os.path.join(HERE, "wrapper32_pywt.npz"), **out)
+    print("wrote wrapper32_pywt.npz:", len(cases), "cases; pywt", pywt.__version__, "numpy", np.__version__)
+
+
 if __name__ == "__main__":
-    {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench}[sys.argv[1]]()
+    {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32}[sys.argv[1]]()
