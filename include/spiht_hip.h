@@ -171,6 +171,20 @@ int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B
                                  int wavelet, int mode, int level, double q_scale, const double *channel_mults,
                                  double *d_img_out);
 
+/* Single-precision forms of the two encode-side entry points: d_img float32 [B,c,H,W].  PyWavelets transforms
+ * float32 (and float16) pixels in float32 and the reference wrapper quantises the float32 array in float32
+ * (`pywt.wavedec2` dtype rule, spiht_wrapper.py:163-172) -- so a float32 image does not give the stream its float64
+ * copy gives; these reproduce the float32 result, including pywt's order of additions at the right / bottom edge.
+ * SPIHT_ERR_ARG when a level's input is shorter than the filter (level above pywt's dwt_max_level) or level == 0.
+ * The decode side is float64 in the reference whatever the pixels were. */
+int spiht_dwt_quant_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                              int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                              int32_t *d_coeffs);
+int spiht_encode_image_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                 int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                 uint64_t max_bits, uint8_t *d_out, uint64_t slot_stride, uint64_t *d_nbits,
+                                 uint8_t *d_max_n, int32_t *d_coeffs);
+
 /* Significance pyramid on its own (device pointers), for parity tests and profiling:
  * d_x int32 [B,c,h,w] -> d_dmsb, d_lmsb uint8 [B,c,h,w] (1 + msb of the D / L set maxima of the node with
  * that index, 0 = empty/zero; only nodes with offspring are written) and d_maxabs uint32 [B]. */

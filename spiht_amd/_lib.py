@@ -39,6 +39,7 @@ SYMBOLS = [
     "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
+    "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
     "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset",
 ]
@@ -97,6 +98,8 @@ def lib():
         L.spiht_decode_image_batch_f64.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double,
                                                    vp, vp, vp]
         L.spiht_dwt_quant_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_dwt_quant_batch_f32.argtypes = L.spiht_dwt_quant_batch_f64.argtypes
+        L.spiht_encode_image_batch_f32.argtypes = L.spiht_encode_image_batch_f64.argtypes
         L.spiht_dequant_idwt_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
         L.spiht_pyramid_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp]
         L.spiht_nbits_to_nbytes.argtypes = [vp, vp, i64, vp]

@@ -55,7 +55,10 @@ class BatchCodec:
     settings / level / max_bits have the meaning of spiht_wrapper.encode_image; colour conversion is not
     applied here (convert before uploading)."""
 
-    def __init__(self, c, H, W, settings=None, level=None, max_bits=None, ctx=None):
+    def __init__(self, c, H, W, settings=None, level=None, max_bits=None, ctx=None, pixel_dtype=np.float64):
+        # pixel_dtype float32: the encoder side runs PyWavelets' single-precision arithmetic (what the reference does
+        # with float32 / float16 pixels); decoded images are float64 either way, as in the reference
+        self.pixel_dtype = np.dtype(np.float32 if np.dtype(pixel_dtype) in (np.float32, np.float16) else np.float64)
         self.settings = settings if settings is not None else SpihtSettings()
         self.c, self.H, self.W, self.level = int(c), int(H), int(W), level
         self.ctx = ctx if ctx is not None else _lib.default_context()
@@ -72,7 +75,8 @@ class BatchCodec:
 
     # ---- raw device-pointer API (ints) -------------------------------------------------------
     def encode_device(self, d_img, B, d_out, d_nbits, d_max_n, d_coeffs=None):
-        _lib.check(self.L.spiht_encode_image_batch_f64(
+        fn = self.L.spiht_encode_image_batch_f32 if self.pixel_dtype == np.float32 else self.L.spiht_encode_image_batch_f64
+        _lib.check(fn(
             self.ctx.handle, C.c_void_p(d_img), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
             float(self.settings.quantization_scale), self._mults_p, self.max_bits, C.c_void_p(d_out),
             self.slot_stride, C.c_void_p(d_nbits), C.c_void_p(d_max_n), C.c_void_p(d_coeffs) if d_coeffs else None))
@@ -90,11 +94,11 @@ class BatchCodec:
     # ---- host convenience ---------------------------------------------------------------------
     def encode(self, images):
         """images: float array [B,c,H,W] -> list of EncodingResult"""
-        images = np.ascontiguousarray(images, dtype=np.float64)
+        images = np.ascontiguousarray(images, dtype=self.pixel_dtype)
         B = images.shape[0]
         assert images.shape[1:] == (self.c, self.H, self.W)
         ctx = self.ctx
-        d_img = DeviceArray(ctx, images.shape, np.float64)
+        d_img = DeviceArray(ctx, images.shape, self.pixel_dtype)
         d_out = DeviceArray(ctx, (B, self.slot_stride), np.uint8)
         d_nbits = DeviceArray(ctx, (B,), np.uint64)
         d_maxn = DeviceArray(ctx, (B,), np.uint8)

@@ -879,10 +879,17 @@ static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, 
 }
 
 // pixels [planes,H,W] -> quantised packed array [planes,enc_h,enc_w]
+// f32: d_img holds float pixels and the transform runs in single precision, as PyWavelets does for float32 / float16
+// input (every level's input must then be at least as long as the filter: SPIHT_ERR_ARG otherwise)
 static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
-                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr) {
+                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false) {
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
+    if (f32) {
+        if (ig.L == 0) return SPIHT_ERR_ARG;
+        for (int l = 1; l <= ig.L; l++)
+            if (ig.hs[l - 1] < wv.F || ig.ws[l - 1] < wv.F) return SPIHT_ERR_ARG;
+    }
     if (ig.L == 0) {
         StageTimer t(ctx, ST_DWT_REST);
         LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, d_maxabs, ctx->stream));
@@ -910,6 +917,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         a.off_h = (int32_t)ig.offh[l]; a.off_w = (int32_t)ig.offw[l];
         a.enc_h = (int32_t)ig.enc_h; a.enc_w = (int32_t)ig.enc_w;
         a.last = (l == ig.L) ? 1 : 0;
+        a.f32 = f32 ? 1 : 0;
         a.in = in;
         a.ll_out = a.last ? nullptr : (double *)((l & 1) ? ctx->a0.p : ctx->a1.p);
         a.coeffs = d_coeffs;
@@ -984,9 +992,10 @@ static int check_img_args(int wavelet, int mode, int64_t B, int64_t c, int64_t H
     return SPIHT_OK;
 }
 
-extern "C" int spiht_dwt_quant_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
-                                         int wavelet, int mode, int level, double q_scale, const double *channel_mults,
-                                         int32_t *d_coeffs) {
+static int dwt_quant_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int64_t B, int64_t c, int64_t H, int64_t W,
+                           int wavelet, int mode, int level, double q_scale, const double *channel_mults, int32_t *d_coeffs) {
+    const double *d_img = (const double *)d_img_v;
+    const size_t esz = f32 ? 4 : 8;
     if (!ctx || !d_img || !d_coeffs) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
@@ -999,10 +1008,20 @@ extern "C" int spiht_dwt_quant_batch_f64(spiht_ctx *ctx, const double *d_img, in
     const int chunk = (int)std::max<int64_t>(1, 65535 / c);
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
-        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults,
-                        d_coeffs + (size_t)b0 * c * ig.enc_h * ig.enc_w));
+        CHK(dwt_forward(ctx, (const double *)((const char *)d_img + (size_t)b0 * c * H * W * esz), nb * (int)c, (int)c, ig, wavelet,
+                        mode, q_scale, d_mults, d_coeffs + (size_t)b0 * c * ig.enc_h * ig.enc_w, nullptr, f32));
     }
     return SPIHT_OK;
+}
+extern "C" int spiht_dwt_quant_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                         int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                         int32_t *d_coeffs) {
+    return dwt_quant_batch(ctx, d_img, false, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, d_coeffs);
+}
+extern "C" int spiht_dwt_quant_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
+                                         int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                         int32_t *d_coeffs) {
+    return dwt_quant_batch(ctx, d_img, true, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, d_coeffs);
 }
 
 extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H,
@@ -1026,11 +1045,12 @@ extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec
     return SPIHT_OK;
 }
 
-extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H,
-                                            int64_t W, int wavelet, int mode, int level, double q_scale,
-                                            const double *channel_mults, uint64_t max_bits, uint8_t *d_out,
-                                            uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n,
-                                            int32_t *d_coeffs) {
+static int encode_image_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int64_t B, int64_t c, int64_t H, int64_t W,
+                              int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                              uint64_t max_bits, uint8_t *d_out, uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n,
+                              int32_t *d_coeffs) {
+    const double *d_img = (const double *)d_img_v;
+    const size_t esz = f32 ? 4 : 8;
     if (!ctx || !d_img || !d_out || !d_nbits || !d_max_n) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
@@ -1052,12 +1072,28 @@ extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img,
         }
         CHK(ensure(ctx, ctx->maxabs, (size_t)nb * 4));
         HIPCHK(hipMemsetAsync(ctx->maxabs.p, 0, (size_t)nb * 4, ctx->stream));
-        CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
-                        (uint32_t *)ctx->maxabs.p));
+        CHK(dwt_forward(ctx, (const double *)((const char *)d_img + (size_t)b0 * c * H * W * esz), nb * (int)c, (int)c, ig, wavelet,
+                        mode, q_scale, d_mults, co, (uint32_t *)ctx->maxabs.p, f32));
         CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
                           d_max_n + b0, true));
     }
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
+}
+extern "C" int spiht_encode_image_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H,
+                                            int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, uint64_t max_bits, uint8_t *d_out,
+                                            uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n,
+                                            int32_t *d_coeffs) {
+    return encode_image_batch(ctx, d_img, false, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, max_bits, d_out,
+                              slot_stride, d_nbits, d_max_n, d_coeffs);
+}
+extern "C" int spiht_encode_image_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, int64_t c, int64_t H,
+                                            int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, uint64_t max_bits, uint8_t *d_out,
+                                            uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_max_n,
+                                            int32_t *d_coeffs) {
+    return encode_image_batch(ctx, d_img, true, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, max_bits, d_out,
+                              slot_stride, d_nbits, d_max_n, d_coeffs);
 }
 
 extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,

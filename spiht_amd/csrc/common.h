@@ -134,6 +134,7 @@ struct DwtKArgs {
     int32_t off_h, off_w, enc_h, enc_w;
     int32_t last;          // coarsest level: LL is quantised into the packed array too
     int32_t planes;        // B*c (set by the launcher)
+    int32_t f32;           // single-precision level (k_dwt_level_f32): `in` / `ll_out` then point to float arrays
     const double *in;      // [planes, in_h, in_w]
     double *ll_out;        // [planes, out_h, out_w]
     int32_t *coeffs;       // [planes, enc_h, enc_w]

@@ -164,6 +164,134 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     }
 }
 
+// ---- single-precision forward level ------------------------------------------------------------------------------
+// PyWavelets transforms float32 (and float16) pixels in float32 with float copies of the filters, and the wrapper
+// quantises the float32 array in float32 (in float64 once per-channel scales are applied).  In float32 the order of
+// the additions decides quantised coefficients, so this kernel follows pywt's (convolution.template.c,
+// downsampling_convolution): ascending taps, except for outputs that hang over the right / bottom end (2o+1 >= N),
+// where the taps reading the extension come first, nearest first (tap index 2o+1-N down to 0), then the rest
+// ascending.  Same tiling as k_dwt_level; the overhang outputs (the last (F-1)/2 rows and columns of a level) take
+// a slower path with run-time tap order.  Level inputs shorter than the filter are refused by the host (pywt runs
+// yet another loop for them).
+__device__ __forceinline__ int32_t quant_f32(float v, double m, double q, float qf, bool has_m) {
+    if (has_m) return (int32_t)((m * (double)v) * q);  // channel_mults[:,None,None] * arr is float64 (wrapper:167-170)
+    return (int32_t)(v * qf);                          // arr * q_scale stays float32 (wrapper:9-11)
+}
+
+template <int F, uint32_t LOM, uint32_t HIM>
+__global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
+    constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
+    static_assert(NC <= DW_BLOCK, "one thread per input column");
+    constexpr int RS = HC + 1, PS = DW_TH * RS + 8;
+    __shared__ float s_lo[2][PS];
+    __shared__ float s_hi[2][PS];
+    __shared__ int s_row[NR];
+    __shared__ float s_flo[F], s_fhi[F];  // float copies of the filters, for the run-time-ordered overhang sums
+    uint32_t tbx, tby, tbz;
+    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+    const int plane = (int)tbz;
+    const int oh0 = (int)tby * DW_TH, ow0 = (int)tbx * DW_TW;
+    const float *__restrict__ in = reinterpret_cast<const float *>(a.in) + (size_t)plane * a.in_h * a.in_w;
+    const int tid = threadIdx.x;
+    float flo[F], fhi[F];
+#pragma unroll
+    for (int j = 0; j < F; j++) { flo[j] = (float)a.lo[j]; fhi[j] = (float)a.hi[j]; }
+
+    const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
+    if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
+    if (tid < F) { s_flo[tid] = (float)a.lo[tid]; s_fhi[tid] = (float)a.hi[tid]; }
+    __syncthreads();
+
+    // ---- axis -2 ----
+    if (tid < NC) {
+        const int gc = ext_index(c0 + tid, a.in_w, a.mode);
+        float x[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int gr = s_row[r];
+            x[r] = (gc < 0 || gr < 0) ? 0.0f : in[(size_t)gr * a.in_w + gc];
+        }
+        const int par = tid & 1, hc = tid >> 1;
+#pragma unroll
+        for (int o = 0; o < DW_TH; o++) {
+            float sl = 0.0f, shh = 0.0f;
+            const int i = 2 * (oh0 + o) + 1;
+            if (i < a.in_h) {
+#pragma unroll
+                for (int j = 0; j < F; j++) {
+                    if ((LOM >> j) & 1u) sl += flo[j] * x[2 * o + F - 1 - j];
+                    if ((HIM >> j) & 1u) shh += fhi[j] * x[2 * o + F - 1 - j];
+                }
+            } else if (oh0 + o < a.out_h) {  // overhang: extension taps first, nearest first (reloaded: run-time order)
+                const int jb = i - a.in_h;
+                for (int s = 0; s < F; s++) {
+                    const int j = s <= jb ? jb - s : s;
+                    const int gr = s_row[2 * o + F - 1 - j];
+                    const float v = (gc < 0 || gr < 0) ? 0.0f : in[(size_t)gr * a.in_w + gc];
+                    sl += s_flo[j] * v;
+                    shh += s_fhi[j] * v;
+                }
+            }
+            s_lo[par][o * RS + hc] = sl;
+            s_hi[par][o * RS + hc] = shh;
+        }
+    }
+    __syncthreads();
+
+    // ---- axis -1 from LDS ----
+    const int k = plane % a.c;
+    const bool has_m = a.mults != nullptr;
+    const double mk = has_m ? a.mults[k] : 1.0;
+    const float qf = (float)a.q;
+    int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+    float *__restrict__ llo = a.last ? nullptr : reinterpret_cast<float *>(a.ll_out) + (size_t)plane * a.out_h * a.out_w;
+    uint32_t amax = 0;
+#pragma unroll
+    for (int u = 0; u < DW_TH * DW_TW / DW_BLOCK; u++) {
+        const int p = tid + u * DW_BLOCK;
+        const int o = p / DW_TW, wcol = p % DW_TW;
+        const int oh = oh0 + o, ow = ow0 + wcol;
+        if (oh >= a.out_h || ow >= a.out_w) continue;
+        float aa = 0.0f, ad = 0.0f, da = 0.0f, dd = 0.0f;
+        const int i = 2 * ow + 1;
+        if (i < a.in_w) {
+#pragma unroll
+            for (int j = 0; j < F; j++) {
+                const float vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                const float vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                if ((LOM >> j) & 1u) { aa += flo[j] * vl; da += flo[j] * vh; }
+                if ((HIM >> j) & 1u) { ad += fhi[j] * vl; dd += fhi[j] * vh; }
+            }
+        } else {
+            const int jb = i - a.in_w;
+            for (int s = 0; s < F; s++) {
+                const int j = s <= jb ? jb - s : s;
+                const float vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                const float vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                aa += s_flo[j] * vl; da += s_flo[j] * vh;
+                ad += s_fhi[j] * vl; dd += s_fhi[j] * vh;
+            }
+        }
+        const int32_t qad = quant_f32(ad, mk, a.q, qf, has_m), qda = quant_f32(da, mk, a.q, qf, has_m),
+                      qdd = quant_f32(dd, mk, a.q, qf, has_m);
+        if (a.last) {
+            const int32_t qaa = quant_f32(aa, mk, a.q, qf, has_m);
+            co[(size_t)oh * a.enc_w + ow] = qaa;
+            amax = max(amax, iabs_u(qaa));
+        } else {
+            llo[(size_t)oh * a.out_w + ow] = aa;
+        }
+        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
+        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
+        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
+        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+
 // ---- row-marching variant of the forward level ------------------------------------------------------------------
 // A workgroup owns a strip of MW_SW output columns and marches down MW_ROWS output rows: thread = input column keeps
 // the F rows its column filter needs in registers (two new rows per step, prefetched MW_PF steps ahead, so every
@@ -432,6 +560,11 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
+    if (a.f32) {
+        uint32_t ntf = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+        hipLaunchKernelGGL((k_dwt_level_f32<F, LOM, HIM>), dim3(ntf), dim3(DW_BLOCK), 0, st, a);
+        return (int)hipGetLastError();
+    }
     static const int use_march = [] { const char *e = getenv("SPIHT_DWT_MARCH"); return e ? atoi(e) : 0; }();
     if (use_march) {
         constexpr int SW = (256 - (F - 2)) / 2;

@@ -144,7 +144,20 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
 
     ctx = _lib.default_context()
     L = _lib.lib()
-    img = np.ascontiguousarray(image, dtype=np.float64)
+    # PyWavelets' dtype rule (_check_dtype): float32 and float16 pixels are transformed in single precision (and then
+    # quantised in single precision, wrapper:163-172), everything else in double
+    f32 = image.dtype in (np.float32, np.float16)
+    img = np.ascontiguousarray(image, dtype=np.float32 if f32 else np.float64)
+    if f32:
+        F = _FILTER_LEN[spiht_settings.wavelet]
+        hh, ww = h, w
+        for _ in range(g["level"]):
+            if hh < F or ww < F:
+                raise ValueError("float32 pixels with a level above pywt.dwt_max_level are not supported "
+                                 "(PyWavelets uses a different summation loop there); pass float64 pixels")
+            hh, ww = (hh + F - 1) // 2, (ww + F - 1) // 2
+        if g["level"] == 0:
+            raise ValueError("float32 pixels with level 0 are not supported; pass float64 pixels")
     bound = C.c_uint64()
     _lib.check(L.spiht_encode_bound(c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], 0x3FFFFFFF, max_bits,
                                     C.byref(bound)))
@@ -154,7 +167,7 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
     d_meta = ctx.alloc(16)
     try:
         ctx.upload(d_img, img)
-        _lib.check(L.spiht_encode_image_batch_f64(
+        _lib.check((L.spiht_encode_image_batch_f32 if f32 else L.spiht_encode_image_batch_f64)(
             ctx.handle, C.c_void_p(d_img), 1, c, h, w, wid, mid, -1 if level is None else int(level),
             float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(d_out), slot,
             C.c_void_p(d_meta), C.c_void_p(d_meta + 8), None))

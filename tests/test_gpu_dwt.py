@@ -146,3 +146,57 @@ def test_quantised_transform_of_bench_images_matches_pywt_digests():
         qa = d_co.download()
         assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == str(dig), (seed, h, w, str(wv))
         d_img.free(); d_co.free()
+
+
+def _w32_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrapper32_pywt.npz"))
+    for i in range(int(z["ncases"])):
+        p = "c%d_" % i
+        seed, c, h, w, lv = [int(v) for v in z[p + "meta"]]
+        mults = z[p + "mults"]
+        yield dict(seed=seed, c=c, h=h, w=w, level=None if lv < 0 else lv, wavelet=str(z[p + "wavelet"]), q=float(z[p + "q"]),
+                   mults=None if mults.size == 0 else mults.tolist(), f16=bool(z[p + "f16"]), sha1=str(z[p + "sha1"]),
+                   quant=z[p + "quant"] if p + "quant" in z.files else None)
+
+
+def test_float32_pixels_follow_pywt_single_precision(oracle):
+    """float32 / float16 pixels: PyWavelets transforms and the wrapper quantises in single precision.  GPU == pywt 1.1.1
+    goldens (tests/golden/wrapper32_pywt.npz) on the int32 arrays handed to the SPIHT core, == oracle, and the streams
+    of encode_image follow"""
+    import ctypes as C
+    import hashlib
+    import spiht_amd
+    from conftest import synth_image
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    ctx, L = _lib.default_context(), _lib.lib()
+    for cs in _w32_cases():
+        c, h, w = cs["c"], cs["h"], cs["w"]
+        img = synth_image(cs["seed"], c, h, w).astype(np.float16 if cs["f16"] else np.float32)
+        wid = L.spiht_wavelet_id(cs["wavelet"].encode())
+        lv = -1 if cs["level"] is None else cs["level"]
+        lvl, v = C.c_int(), [C.c_int64() for _ in range(6)]
+        _lib.check(L.spiht_geometry(h, w, wid, lv, C.byref(lvl), *[C.byref(t) for t in v]))
+        enc_h, enc_w = v[2].value, v[3].value
+        d_img = DeviceArray(ctx, (c, h, w), np.float32)
+        d_co = DeviceArray(ctx, (c, enc_h, enc_w), np.int32)
+        d_img.upload(img.astype(np.float32))
+        m = None if cs["mults"] is None else np.ascontiguousarray(cs["mults"], dtype=np.float64)
+        _lib.check(L.spiht_dwt_quant_batch_f32(ctx.handle, C.c_void_p(d_img.ptr), 1, c, h, w, wid, 0, lv, cs["q"],
+                                               None if m is None else C.c_void_p(m.ctypes.data), C.c_void_p(d_co.ptr)))
+        ctx.synchronize()
+        qa = d_co.download()
+        d_img.free(); d_co.free()
+        if cs["quant"] is not None:
+            assert np.array_equal(qa, cs["quant"]), (cs["seed"], "vs pywt array")
+        assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == cs["sha1"], (cs["seed"], h, w)
+        # the wrapper picks the single-precision path from the dtype, and the stream equals the oracle's
+        s = spiht_amd.SpihtSettings(wavelet=cs["wavelet"], quantization_scale=cs["q"], per_channel_quant_scales=cs["mults"])
+        mb = 20000
+        enc = spiht_amd.encode_image(img, s, level=cs["level"], max_bits=mb)
+        ref_bytes, ref_n, _ = oracle.encode_image(img, cs["wavelet"], "reflect", cs["level"], cs["q"], cs["mults"], mb)
+        assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n
+        enc64 = spiht_amd.encode_image(img.astype(np.float64), s, level=cs["level"], max_bits=mb)
+        assert enc64.encoded_bytes == oracle.encode_image(img.astype(np.float64), cs["wavelet"], "reflect", cs["level"], cs["q"],
+                                                          cs["mults"], mb)[0]

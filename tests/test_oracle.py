@@ -231,3 +231,22 @@ def test_quantised_transform_of_bench_images_matches_pywt(oracle):
         arr = arr[0] if isinstance(arr, tuple) else arr
         qa = np.ascontiguousarray(oracle.quantize(arr, q))
         assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == dig, (seed, h, w, wv)
+
+
+def test_float32_forward_path_is_bit_identical_to_pywt(oracle):
+    """tests/golden/wrapper32_pywt.npz: PyWavelets 1.1.1 on float32 / float16 pixels (single precision, its own order of
+    additions at the right and bottom edge) and the wrapper's single-precision quantisation"""
+    import hashlib
+    from conftest import synth_image
+    z = np.load(os.path.join(GOLD, "wrapper32_pywt.npz"))
+    for i in range(int(z["ncases"])):
+        p = "c%d_" % i
+        seed, c, h, w, lv = [int(v) for v in z[p + "meta"]]
+        mults = z[p + "mults"]
+        img = synth_image(seed, c, h, w).astype(np.float16 if bool(z[p + "f16"]) else np.float32)
+        arr, _ = oracle.wavedec2_array_f32(img, str(z[p + "wavelet"]), "reflect", None if lv < 0 else lv)
+        qa = oracle.quantize_f32(arr, float(z[p + "q"]), None if mults.size == 0 else mults)
+        if p + "arr" in z.files:
+            assert np.array_equal(arr.view(np.uint32), z[p + "arr"].view(np.uint32))  # every bit of every float
+            assert np.array_equal(qa, z[p + "quant"])
+        assert hashlib.sha1(np.ascontiguousarray(qa).tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == str(z[p + "sha1"])
