@@ -53,6 +53,10 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--cpu-sample", type=int, default=24,
                     help="images the CPU baseline codes, cycling through the distinct ones (0 = skip); 24 = about 11 s of one core")
+    ap.add_argument("--pixels", choices=["float64", "float32"], default="float64",
+                    help="pixel dtype.  float64 (default) is what the reference's loader produces and what the metric is quoted "
+                         "on; float32 runs the single-precision forward transform PyWavelets would run on such pixels (half the "
+                         "DWT read traffic); the decode side is float64 either way, as in the reference")
     ap.add_argument("--pipeline", type=int, default=0,
                     help="1: steps are software-pipelined over two contexts -- the HBM-bound halves (DWT + pyramid of step "
                          "i+1, inverse DWT of step i-1) run while the list coder works on step i "
@@ -87,7 +91,8 @@ def main():
     max_bits = int(H * W * BPP)  # demonstrate.py:50
     K = max(1, min(args.streams, B))
     ctxs = [ctx] + [_lib.Context(local_rank) for _ in range(K - 1)]
-    codecs = [BatchCodec(C_IMG, H, W, SpihtSettings(WAVELET, QSCALE, MODE), LEVEL, max_bits, ctx=cx) for cx in ctxs]
+    pix = np.dtype(args.pixels)
+    codecs = [BatchCodec(C_IMG, H, W, SpihtSettings(WAVELET, QSCALE, MODE), LEVEL, max_bits, ctx=cx, pixel_dtype=pix) for cx in ctxs]
     codec = codecs[0]
     g = codec.geom
     slot = codec.slot_stride
@@ -96,8 +101,8 @@ def main():
     # ---- synthetic inputs, resident in HBM before the timed region ----
     nd = max(1, min(args.distinct, B))
     base = [synth_image(1000 + rank * nd + i, C_IMG, H, W) for i in range(nd)]
-    d_img = DeviceArray(ctx, (B, C_IMG, H, W), np.float64)
-    per = C_IMG * H * W * 8
+    d_img = DeviceArray(ctx, (B, C_IMG, H, W), pix)
+    per = C_IMG * H * W * pix.itemsize
     for b in range(B):
         d_img.upload(base[b % nd], offset_bytes=b * per)
     d_rec_img = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
@@ -117,7 +122,7 @@ def main():
         d_maxn = DeviceArray(ctx, (B,), np.uint8)
         out_ptr, nbits_ptr, maxn_ptr = d_out.ptr, d_nbits.ptr, d_maxn.ptr
 
-    img_b = C_IMG * H * W * 8
+    img_b = C_IMG * H * W * pix.itemsize
     rec_b = C_IMG * g["rec_h"] * g["rec_w"] * 8
 
     def enc_chunk(k):
@@ -130,7 +135,7 @@ def main():
         codecs[k].decode_device(out_ptr + a * slot, d_nbytes.ptr + a * 8, maxn_ptr + a, b - a, d_rec_img.ptr + a * rec_b)
 
     pipe = None
-    if args.pipeline and K == 1:
+    if args.pipeline and K == 1 and pix == np.float64:
         # The HBM-bound halves (DWT+pyramid of step i+1, zero-fill, inverse DWT of step i-1) run on context H while
         # context L list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).
         from spiht_amd.batch import OverlappedCodec
@@ -225,14 +230,14 @@ def main():
         # algorithmic bytes of one forward-DWT level-1 launch over the whole batch:
         # read the float64 image once, write LL as float64 and the three detail bands as int32
         per_launch = bounds[0][1] - bounds[0][0]  # images one launch covers (chunk size)
-        dwt_bytes = per_launch * C_IMG * (H * W * 8 + h1 * w1 * 8 + 3 * h1 * w1 * 4)
+        dwt_bytes = per_launch * C_IMG * (H * W * pix.itemsize + h1 * w1 * pix.itemsize + 3 * h1 * w1 * 4)
         ms_l1, n_l1 = stages.get("dwt_level1", (0.0, 0))
         avg_ms = ms_l1 / n_l1 if n_l1 else float("nan")
         achieved = dwt_bytes / (avg_ms * 1e-3) / 1e9 if n_l1 else float("nan")
         # HBM traffic of that kernel from PMC counters (tools/collect_traffic.py; separate rocprofv3 --pmc passes)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dwt_l1_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and pix == np.float64:
             try:
                 traffic = round(json.load(open(tpath))["hbm_bytes_per_image"] * per_launch)
             except Exception:
@@ -265,7 +270,7 @@ def main():
         n_par = C_IMG * (g["enc_h"] // 2) * (g["enc_w"] // 2)
         other = {
             # inverse level 1: read 3 int32 bands + float64 LL, write the float64 image
-            "idwt_level1": _gbs("idwt_level1", dwt_bytes),
+            "idwt_level1": _gbs("idwt_level1", per_launch * C_IMG * (H * W * 8 + h1 * w1 * 8 + 3 * h1 * w1 * 4)),
             # significance pyramid: read 4 B per coefficient, write 1 B per parent (D) + 1 B per grand-parent (L)
             "pyramid": _gbs("pyramid", per_launch * (4 * n_coef + n_par + n_par // 4)),
         }
@@ -280,7 +285,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 DWT / int32 bit-plane coding",
+            "dtype": ("f64" if pix == np.float64 else "f32 forward / f64 inverse") + " DWT / int32 bit-plane coding",
             "data": "synthetic",
             "config": {"workload": "cfg2 image (1920x1080 RGB, bior2.2 reflect level 7, q=50, 0.5 bpp) x %d per GPU "
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
@@ -288,7 +293,8 @@ def main():
                        "schedule": ("steps software-pipelined over two contexts: HBM-bound passes of steps i+1 / i-1 run "
                                     "while step i is list-coded" if pipe is not None else "stages back to back"), "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]]},
-            "roofline": {"bound": "hbm", "kernel": "k_dwt_level<6> (forward DWT level 1, fused quantise)",
+            "roofline": {"bound": "hbm", "kernel": ("k_dwt_level<6>" if pix == np.float64 else "k_dwt_level_f32<6>") +
+                         " (forward DWT level 1, fused quantise)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4)},
@@ -306,7 +312,7 @@ def main():
             tc = time.perf_counter()
             streams = []
             for i in range(ns):
-                data, mn, _ = O.encode_image(base[i % nd], WAVELET, MODE, LEVEL, QSCALE, None, max_bits)
+                data, mn, _ = O.encode_image(base[i % nd].astype(pix), WAVELET, MODE, LEVEL, QSCALE, None, max_bits)
                 streams.append((data, mn))
             t_enc = time.perf_counter() - tc
             tc = time.perf_counter()
