@@ -169,21 +169,25 @@ static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, c
     }
 }
 
-/* 1-D synthesis along a strided line; output length 2L-F+2 */
+/* 1-D synthesis along a strided line; output length 2L-F+2.  Order of the additions as in pywt's
+ * upsampling_convolution_valid_sf (convolution.template.c): the approximation part and the detail part are two separate
+ * sums, each over j = 0..F/2-1 with taps 2j (even outputs) / 2j+1 (odd outputs) against input i-j, and the detail sum is
+ * added to the finished approximation sum (idwt: `output += ...` twice). */
 static void idwt_line(const double *ca, const double *cd, int64_t L, int64_t si, const double *lo,
                       const double *hi, int F, double *x, int64_t so) {
     int64_t N = 2 * L - F + 2;
     for (int64_t n = 0; n < N; n++) {
-        double s = 0.0;
-        /* only k with tap index t = n+F-2-2k in [0,F) contribute: k in [ceil((n-1)/2), floor((n+F-2)/2)] */
-        int64_t k_hi = (n + F - 2) / 2;
-        if (k_hi > L - 1) k_hi = L - 1;
-        for (int64_t k = n / 2; k <= k_hi; k++) {
-            int64_t t = n + F - 2 - 2 * k;
-            if (t < 0 || t >= F) continue;
-            s += ca[k * si] * lo[t] + cd[k * si] * hi[t];
+        /* output n = 2(i - (F/2-1)) + p  with p = n & 1:  i = n/2 + F/2 - 1;  term j uses tap 2j+p and input i-j */
+        int64_t i = n / 2 + F / 2 - 1;
+        int p = (int)(n & 1);
+        double sa = 0.0, sd = 0.0;
+        for (int j = 0; j < F / 2; j++) {
+            int64_t k = i - j;
+            if (k < 0 || k >= L) continue;
+            sa += lo[2 * j + p] * ca[k * si];
+            sd += hi[2 * j + p] * cd[k * si];
         }
-        x[n * so] = s;
+        x[n * so] = (0.0 + sa) + sd;
     }
 }
 

@@ -514,24 +514,27 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 #pragma unroll
     for (int rr = 0; rr < KHH; rr++) {
         const int r = rbase + rr;
-        // axis -1 synthesis of band row r at output column n (ascending band column)
-        double tl = 0.0, th = 0.0;
+        // axis -1 synthesis of band row r at output column n.  Order of the additions as in pywt's
+        // upsampling_convolution_valid_sf: the approximation and the detail contribution are separate sums, each over
+        // j = 0..F/2-1 (tap 2j+parity against band column i-j, i.e. DEscending band column), and the detail sum is
+        // added to the finished approximation sum -- the result is then bit-identical to pywt.waverec2's.
+        double ta = 0.0, td = 0.0, ua = 0.0, ud = 0.0;
 #pragma unroll
-        for (int s = 0; s < HF; s++) {
+        for (int j = 0; j < HF; j++) {
+            const int s = HF - 1 - j;
             // taps F-2-2s (even columns) and F-1-2s (odd columns): skip a product when both are zero
             constexpr uint32_t PAIR = 3u;
             const bool lnz = ((LOM >> (F - 2 - 2 * s)) & PAIR) != 0, hnz = ((HIM >> (F - 2 - 2 * s)) & PAIR) != 0;
-            if (lnz && hnz) {
-                tl += s_b[0][r][cl + s] * tlo[s] + s_b[1][r][cl + s] * thi[s];
-                th += s_b[2][r][cl + s] * tlo[s] + s_b[3][r][cl + s] * thi[s];
-            } else if (lnz) {
-                tl += s_b[0][r][cl + s] * tlo[s];
-                th += s_b[2][r][cl + s] * tlo[s];
-            } else if (hnz) {
-                tl += s_b[1][r][cl + s] * thi[s];
-                th += s_b[3][r][cl + s] * thi[s];
+            if (lnz) {
+                ta += s_b[0][r][cl + s] * tlo[s];
+                ua += s_b[2][r][cl + s] * tlo[s];
+            }
+            if (hnz) {
+                td += s_b[1][r][cl + s] * thi[s];
+                ud += s_b[3][r][cl + s] * thi[s];
             }
         }
+        const double tl = (0.0 + ta) + td, th = (0.0 + ua) + ud;
 #pragma unroll
         for (int s = 0; s < HF - 1; s++) { wl[s] = wl[s + 1]; wh[s] = wh[s + 1]; }
         wl[HF - 1] = tl;
@@ -541,14 +544,15 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
             const int m = 2 * (kh0 + r - (HF - 1));
 #pragma unroll
             for (int mp = 0; mp < 2; mp++) {
-                double sacc = 0.0;
+                double sa = 0.0, sd = 0.0;  // same order along axis -2
 #pragma unroll
-                for (int s = 0; s < HF; s++) {
+                for (int j = 0; j < HF; j++) {
+                    const int s = HF - 1 - j;
                     const bool lnz = (LOM >> (mp + F - 2 - 2 * s)) & 1u, hnz = (HIM >> (mp + F - 2 - 2 * s)) & 1u;
-                    if (lnz && hnz) sacc += wl[s] * a.lo[mp + F - 2 - 2 * s] + wh[s] * a.hi[mp + F - 2 - 2 * s];
-                    else if (lnz) sacc += wl[s] * a.lo[mp + F - 2 - 2 * s];
-                    else if (hnz) sacc += wh[s] * a.hi[mp + F - 2 - 2 * s];
+                    if (lnz) sa += wl[s] * a.lo[mp + F - 2 - 2 * s];
+                    if (hnz) sd += wh[s] * a.hi[mp + F - 2 - 2 * s];
                 }
+                const double sacc = (0.0 + sa) + sd;
                 if (m + mp < a.out_h && n < a.out_w) out[(size_t)(m + mp) * a.out_w + n] = sacc;
             }
         }

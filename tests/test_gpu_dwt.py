@@ -86,7 +86,7 @@ def test_inverse_matches_pywt_goldens_and_oracle(oracle):
         got = _gpu_idwt(cs["rec"][None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], cs["mults"])[0]
         assert got.shape == cs["rec_img"].shape
         # tolerance vs pywt: summation order differs
-        assert np.abs(got - cs["rec_img"]).max() < 1e-13
+        assert np.array_equal(got, cs["rec_img"])  # bit-identical to pywt.waverec2 (same order of additions)
         ref = oracle.waverec2_array(oracle.dequantize(cs["rec"], cs["q"], cs["mults"]), cs["H"], cs["W"], cs["wavelet"],
                                     cs["level"])
         # same summation order as the oracle: bit for bit
