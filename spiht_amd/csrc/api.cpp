@@ -273,9 +273,14 @@ static void list_caps(const Geom &g, uint64_t max_bits, ListCaps *caps, uint64_t
     uint64_t mb = max_bits;
     uint64_t lip = nodes, lsp = nodes, lis = parents + 4 * roots;  // + leaf A entries under root B entries (Q5)
     if (mb < (1ull << 40)) {
-        lip = std::min(lip, roots + mb);
-        lsp = std::min(lsp, mb / 2 + 1);
-        lis = std::min(lis, roots + 4 * mb);
+        // what a stream of mb bits can put on the lists ... plus what ONE chunk of the encoder appends: its scans
+        // give every entry of the chunk its list slots before the bit budget cuts the chunk short (encode.hip:
+        // up to 2048 LIP entries or 1024 LIS entries per chunk, at most four appends each; found by
+        // tests/test_gpu_spiht.py::test_random_geometries_and_budgets)
+        const uint64_t chunk_slack = 4096;
+        lip = std::min(lip, roots + mb + chunk_slack);
+        lsp = std::min(lsp, mb / 2 + 1 + chunk_slack);
+        lis = std::min(lis, roots + 4 * mb + chunk_slack);
     }
     // multiples of 64 entries: every slot's lists start 256-byte aligned (the encoder reads entry pairs as 8-byte loads)
     caps->lip = (uint32_t)std::min<uint64_t>((lip + 127) & ~63ull, 0xFFFFFFC0ull);

@@ -168,3 +168,39 @@ def test_medium_realistic(oracle):
     full, n, total = oracle.encode_nbits(x, 13, 19, UNLIMITED)
     for nb in [1000, 12345 // 8, len(full) // 3, len(full) - 1]:
         _check_decode(oracle, full[:nb], n, x.shape, 13, 19)
+
+
+def test_random_geometries_and_budgets(oracle):
+    """seeded random sweep: channels, odd / even sizes, LL blocks of every parity, magnitudes from 0 to 2^29, budgets
+    from a few bits to unlimited -- stream, max_n and decoded array against the oracle, decode of random prefixes too"""
+    import spiht_amd
+    rng = np.random.default_rng(20261004)
+    done = 0
+    while done < 48:
+        c = int(rng.integers(1, 5))
+        lh, lw = int(rng.integers(2, 9)), int(rng.integers(2, 9))
+        need_h = 2 * lh if lh % 2 == 0 else 2 * lh - 1
+        need_w = 2 * lw if lw % 2 == 0 else 2 * lw - 1
+        h, w = int(rng.integers(need_h, need_h + 70)), int(rng.integers(need_w, need_w + 70))
+        kind = done % 4
+        if kind == 0:
+            x = synth_coeffs(int(rng.integers(1 << 30)), c, h, w, lh, lw, scale=float(10 ** rng.uniform(0.5, 4.5)))
+        elif kind == 1:
+            x = rng.integers(-3, 4, (c, h, w)).astype(np.int32)                      # tiny values, many zeros
+        elif kind == 2:
+            x = np.zeros((c, h, w), np.int32)
+            idx = rng.integers(0, x.size, 12)
+            x.reshape(-1)[idx] = rng.integers(-(1 << 29), 1 << 29, 12)               # a few huge coefficients
+        else:
+            x = (rng.laplace(0, 1, (c, h, w)) * 200).astype(np.int32)
+            x[:, h // 2:, :] = 0                                                     # an empty half
+        mb = [int(rng.integers(1, 400)), int(rng.integers(400, 20000)), UNLIMITED][done % 3]
+        try:
+            d, n = _check_encode(oracle, x, lh, lw, mb)
+            _check_decode(oracle, d, n, (c, h, w), lh, lw)
+            if len(d) > 2:
+                _check_decode(oracle, d[: int(rng.integers(1, len(d)))], n, (c, h, w), lh, lw)
+        except Exception as e:
+            raise AssertionError("case %d: c=%d h=%d w=%d ll=%dx%d kind=%d max_bits=%d max|x|=%d: %r"
+                                 % (done, c, h, w, lh, lw, kind, mb, int(np.abs(x).max()), e))
+        done += 1
