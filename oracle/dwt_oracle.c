@@ -352,7 +352,8 @@ static void dwt_line_f(const float *x, int64_t N, int64_t sx, const float *lo, c
     int64_t L = (N + F - 1) / 2;
     for (int64_t o = 0; o < L; o++) {
         volatile float a = 0.0f, d = 0.0f; /* volatile: no contraction, no reassociation, no excess precision */
-        int64_t i = 2 * o + 1, jb = i >= N ? i - N : -1;
+        /* constant-edge mode: pywt adds the replicated-edge taps in ascending order too, i.e. plain ascending everywhere */
+        int64_t i = 2 * o + 1, jb = (i >= N && mode != MODE_CONSTANT) ? i - N : -1;
         for (int s = 0; s < F; s++) {
             int j = s <= jb ? (int)(jb - s) : s;
             int64_t idx = ext_index(i - j, N, mode);

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
         for (int o = 0; o < DW_TH; o++) {
             float sl = 0.0f, shh = 0.0f;
             const int i = 2 * (oh0 + o) + 1;
-            if (i < a.in_h) {
+            if (i < a.in_h || a.mode == 4) {  // (constant-edge mode: pywt keeps ascending order over the overhang too)
 #pragma unroll
                 for (int j = 0; j < F; j++) {
                     if ((LOM >> j) & 1u) sl += flo[j] * x[2 * o + F - 1 - j];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
         if (oh >= a.out_h || ow >= a.out_w) continue;
         float aa = 0.0f, ad = 0.0f, da = 0.0f, dd = 0.0f;
         const int i = 2 * ow + 1;
-        if (i < a.in_w) {
+        if (i < a.in_w || a.mode == 4) {
 #pragma unroll
             for (int j = 0; j < F; j++) {
                 const float vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];

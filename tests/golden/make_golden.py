@@ -240,11 +240,16 @@ def part_wrapper32():
     cases = [(21, 3, 64, 80, "bior2.2", 3, 50.0, None), (22, 1, 57, 43, "bior4.4", 2, 10.0, None),
              (23, 3, 96, 128, "bior2.2", None, 50.0, [50.0, 15.0, 15.0]), (24, 3, 511, 733, "bior2.2", None, 50.0, None),
              (1000, 3, 1080, 1920, "bior2.2", 7, 50.0, None), (25, 1, 300, 301, "bior6.8", 3, 33.3, None),
-             (26, 3, 257, 255, "bior2.2", 4, 0.1, None)]
+             (26, 3, 257, 255, "bior2.2", 4, 0.1, None),
+             (27, 2, 61, 77, "bior2.2", 2, 50.0, None, "symmetric"), (28, 1, 64, 48, "bior4.4", None, 50.0, None, "periodic"),
+             (29, 3, 45, 52, "bior2.2", 1, 50.0, None, "zero"), (30, 2, 61, 77, "bior6.8", 2, 50.0, None, "constant"),
+             (31, 1, 50, 41, "haar", 3, 20.0, None, "symmetric")]
     out = {"ncases": np.array(len(cases))}
-    for i, (seed, c, h, w, wv, lv, q, mults) in enumerate(cases):
+    for i, cs in enumerate(cases):
+        seed, c, h, w, wv, lv, q, mults = cs[:8]
+        mode = cs[8] if len(cs) > 8 else "reflect"
         img = synth_image(seed, c, h, w).astype(np.float32 if i != 1 else np.float16)
-        arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wavelet=wv, level=lv, mode="reflect"), axes=(-2, -1))
+        arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wavelet=wv, level=lv, mode=mode), axes=(-2, -1))
         assert arr.dtype == np.float32
         a2 = arr
         if mults is not None:
@@ -253,6 +258,7 @@ def part_wrapper32():
         p = "c%d_" % i
         out[p + "meta"] = np.array([seed, c, h, w, -1 if lv is None else lv])
         out[p + "wavelet"] = np.array(wv)
+        out[p + "mode"] = np.array(mode)
         out[p + "q"] = np.array(q)
         out[p + "mults"] = np.array(mults if mults else [], dtype=np.float64)
         out[p + "f16"] = np.array(i == 1)

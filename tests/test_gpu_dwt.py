@@ -157,6 +157,7 @@ def _w32_cases():
         mults = z[p + "mults"]
         yield dict(seed=seed, c=c, h=h, w=w, level=None if lv < 0 else lv, wavelet=str(z[p + "wavelet"]), q=float(z[p + "q"]),
                    mults=None if mults.size == 0 else mults.tolist(), f16=bool(z[p + "f16"]), sha1=str(z[p + "sha1"]),
+                   mode=str(z[p + "mode"]),
                    quant=z[p + "quant"] if p + "quant" in z.files else None)
 
 
@@ -183,7 +184,7 @@ def test_float32_pixels_follow_pywt_single_precision(oracle):
         d_co = DeviceArray(ctx, (c, enc_h, enc_w), np.int32)
         d_img.upload(img.astype(np.float32))
         m = None if cs["mults"] is None else np.ascontiguousarray(cs["mults"], dtype=np.float64)
-        _lib.check(L.spiht_dwt_quant_batch_f32(ctx.handle, C.c_void_p(d_img.ptr), 1, c, h, w, wid, 0, lv, cs["q"],
+        _lib.check(L.spiht_dwt_quant_batch_f32(ctx.handle, C.c_void_p(d_img.ptr), 1, c, h, w, wid, _lib.MODES[cs["mode"]], lv, cs["q"],
                                                None if m is None else C.c_void_p(m.ctypes.data), C.c_void_p(d_co.ptr)))
         ctx.synchronize()
         qa = d_co.download()
@@ -192,11 +193,12 @@ def test_float32_pixels_follow_pywt_single_precision(oracle):
             assert np.array_equal(qa, cs["quant"]), (cs["seed"], "vs pywt array")
         assert hashlib.sha1(qa.tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == cs["sha1"], (cs["seed"], h, w)
         # the wrapper picks the single-precision path from the dtype, and the stream equals the oracle's
-        s = spiht_amd.SpihtSettings(wavelet=cs["wavelet"], quantization_scale=cs["q"], per_channel_quant_scales=cs["mults"])
+        s = spiht_amd.SpihtSettings(wavelet=cs["wavelet"], quantization_scale=cs["q"], per_channel_quant_scales=cs["mults"],
+                                    mode=cs["mode"])
         mb = 20000
         enc = spiht_amd.encode_image(img, s, level=cs["level"], max_bits=mb)
-        ref_bytes, ref_n, _ = oracle.encode_image(img, cs["wavelet"], "reflect", cs["level"], cs["q"], cs["mults"], mb)
+        ref_bytes, ref_n, _ = oracle.encode_image(img, cs["wavelet"], cs["mode"], cs["level"], cs["q"], cs["mults"], mb)
         assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n
         enc64 = spiht_amd.encode_image(img.astype(np.float64), s, level=cs["level"], max_bits=mb)
-        assert enc64.encoded_bytes == oracle.encode_image(img.astype(np.float64), cs["wavelet"], "reflect", cs["level"], cs["q"],
+        assert enc64.encoded_bytes == oracle.encode_image(img.astype(np.float64), cs["wavelet"], cs["mode"], cs["level"], cs["q"],
                                                           cs["mults"], mb)[0]

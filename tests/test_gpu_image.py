@@ -297,3 +297,39 @@ def test_progressive_prefixes_in_one_batch(oracle):
         assert np.array_equal(im[:, :H, :W], one)
         errs.append(float(np.abs(one - img).mean()))
     assert errs[-1] < errs[3] < errs[0] and errs[-1] < 0.01
+
+
+def test_random_images_settings_and_budgets(oracle):
+    """seeded random sweep over image sizes, wavelets, extension modes, levels, quantisation and per-channel scales,
+    pixel dtype (float64 / float32) and bit budgets: streams, max_n and decoded images against the oracle"""
+    import spiht_amd
+    rng = np.random.default_rng(4102026)
+    wavelets = ["bior2.2", "bior2.2", "bior4.4", "bior6.8", "haar"]
+    for case in range(28):
+        c = int(rng.integers(1, 4))
+        wv = wavelets[int(rng.integers(len(wavelets)))]
+        F = {"bior2.2": 6, "bior4.4": 10, "bior6.8": 18, "haar": 2}[wv]
+        H, W = int(rng.integers(2 * F + 8, 150)), int(rng.integers(2 * F + 8, 150))
+        f32 = bool(case % 3 == 2)
+        mode = ["reflect", "symmetric", "periodic", "zero", "constant"][int(rng.integers(5))]
+        maxlv = int(np.floor(np.log2(min(H, W) / (F - 1)))) if F > 2 else int(np.floor(np.log2(min(H, W))))
+        level = [None, 1, 2, max(1, maxlv)][int(rng.integers(4))]
+        q = float([50.0, 10.0, 255.0, 3.3][int(rng.integers(4))])
+        mults = None if rng.integers(2) else [float(v) for v in rng.uniform(0.2, 3.0, c).round(2)]
+        mb = [None, int(rng.integers(8, 600)), int(rng.integers(600, 40000))][case % 3 if not f32 else int(rng.integers(3))]
+        img = synth_image(int(rng.integers(1 << 30)), c, H, W)
+        if f32:
+            img = img.astype(np.float32)
+        s = spiht_amd.SpihtSettings(wavelet=wv, quantization_scale=q, mode=mode, per_channel_quant_scales=mults)
+        tag = "case %d: c=%d %dx%d %s %s level=%s q=%g mults=%s max_bits=%s %s" % (case, c, H, W, wv, mode, level, q, mults, mb,
+                                                                                    img.dtype)
+        try:
+            enc = spiht_amd.encode_image(img, s, level=level, max_bits=mb)
+        except ValueError as e:
+            assert f32 and "float32" in str(e), tag  # a level above pywt.dwt_max_level in single precision
+            continue
+        ref_bytes, ref_n, g = oracle.encode_image(img, wv, mode, level, q, mults, mb)
+        assert enc.max_n == ref_n and enc.encoded_bytes == ref_bytes, tag
+        dec = spiht_amd.decode_image(enc, s)
+        ref = oracle.decode_image(ref_bytes, ref_n, c, H, W, wv, level, q, mults)
+        assert np.array_equal(dec, ref), tag

@@ -244,7 +244,7 @@ def test_float32_forward_path_is_bit_identical_to_pywt(oracle):
         seed, c, h, w, lv = [int(v) for v in z[p + "meta"]]
         mults = z[p + "mults"]
         img = synth_image(seed, c, h, w).astype(np.float16 if bool(z[p + "f16"]) else np.float32)
-        arr, _ = oracle.wavedec2_array_f32(img, str(z[p + "wavelet"]), "reflect", None if lv < 0 else lv)
+        arr, _ = oracle.wavedec2_array_f32(img, str(z[p + "wavelet"]), str(z[p + "mode"]), None if lv < 0 else lv)
         qa = oracle.quantize_f32(arr, float(z[p + "q"]), None if mults.size == 0 else mults)
         if p + "arr" in z.files:
             assert np.array_equal(arr.view(np.uint32), z[p + "arr"].view(np.uint32))  # every bit of every float
