@@ -305,7 +305,7 @@ def test_random_images_settings_and_budgets(oracle):
     import spiht_amd
     rng = np.random.default_rng(4102026)
     wavelets = ["bior2.2", "bior2.2", "bior4.4", "bior6.8", "haar"]
-    for case in range(28):
+    for case in range(int(__import__("os").environ.get("SPIHT_SWEEP_N", "28"))):
         c = int(rng.integers(1, 4))
         wv = wavelets[int(rng.integers(len(wavelets)))]
         F = {"bior2.2": 6, "bior4.4": 10, "bior6.8": 18, "haar": 2}[wv]
@@ -327,6 +327,11 @@ def test_random_images_settings_and_budgets(oracle):
             enc = spiht_amd.encode_image(img, s, level=level, max_bits=mb)
         except ValueError as e:
             assert f32 and "float32" in str(e), tag  # a level above pywt.dwt_max_level in single precision
+            continue
+        except spiht_amd.spiht.PanicException:
+            # an LL block of a single row / column (e.g. haar at its maximal level): the Rust core asserts ll > 1
+            with pytest.raises(oracle.OraclePanic):
+                oracle.encode_image(img, wv, mode, level, q, mults, mb)
             continue
         ref_bytes, ref_n, g = oracle.encode_image(img, wv, mode, level, q, mults, mb)
         assert enc.max_n == ref_n and enc.encoded_bytes == ref_bytes, tag

@@ -147,3 +147,27 @@ def test_wrapper_return_metadata(oracle):
         r_ref, m_ref = oracle.decode_with_metadata(enc.encoded_bytes, enc.max_n, 3, enc_h, enc_w, ll_h, ll_w, top, other)
         assert meta.shape == (8 * len(enc.encoded_bytes) + 1, 8)
         assert np.array_equal(meta, m_ref)
+
+
+def test_metadata_random_sweep(oracle):
+    """seeded random geometries, budgets and truncation points: every metadata row against the oracle"""
+    import os
+    import spiht_amd
+    rng = np.random.default_rng(777)
+    for case in range(int(os.environ.get("SPIHT_SWEEP_N", "40"))):
+        c = int(rng.integers(1, 4))
+        lh, lw = int(rng.integers(2, 8)), int(rng.integers(2, 8))
+        need_h = 2 * lh if lh % 2 == 0 else 2 * lh - 1
+        need_w = 2 * lw if lw % 2 == 0 else 2 * lw - 1
+        h, w = int(rng.integers(need_h, need_h + 50)), int(rng.integers(need_w, need_w + 50))
+        G = tree_generations(h, w, lh, lw)
+        top, other = nominal_slices(lh, lw, G + int(rng.integers(0, 2)))
+        x = synth_coeffs(int(rng.integers(1 << 30)), c, h, w, lh, lw, scale=float(10 ** rng.uniform(0.5, 3.5)))
+        mb = [int(rng.integers(1, 300)), int(rng.integers(300, 9000)), UNLIMITED][case % 3]
+        d, n = spiht_amd.encode(x, lh, lw, mb)
+        if len(d) > 1 and case % 2:
+            d = d[: int(rng.integers(0, len(d)))]
+        try:
+            _check(oracle, d, n, (c, h, w), lh, lw, top, other)
+        except AssertionError as e:
+            raise AssertionError("case %d: c=%d h=%d w=%d ll=%dx%d max_bits=%d bytes=%d: %s" % (case, c, h, w, lh, lw, mb, len(d), e))

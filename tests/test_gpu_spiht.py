@@ -176,7 +176,8 @@ def test_random_geometries_and_budgets(oracle):
     import spiht_amd
     rng = np.random.default_rng(20261004)
     done = 0
-    while done < 48:
+    n_cases = int(os.environ.get("SPIHT_SWEEP_N", "48"))  # larger sweeps on demand
+    while done < n_cases:
         c = int(rng.integers(1, 5))
         lh, lw = int(rng.integers(2, 9)), int(rng.integers(2, 9))
         need_h = 2 * lh if lh % 2 == 0 else 2 * lh - 1
