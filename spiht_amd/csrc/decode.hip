@@ -3,19 +3,18 @@
 // Reproduces /root/reference/src/encoder_decoder.rs:307-454 on all 8*nbytes bits of the stream
 // (src/lib.rs:38 hands the pad bits to the decoder as data).  Unlike the encoder, the position of a list
 // entry's bits depends on every bit decoded before it.  What is truly serial is only WHERE each entry's bits
-// start; everything else (values, list appends) is data parallel once that is known.  So wavefront 0 is a
-// sequencer that only finds boundaries, one 64-bit stream window at a time, and hands each window to one of
-// the worker wavefronts through an LDS ring:
-//   * LIP pass: tokens are '0' | '1 s'.  The token-start mask of a window is computed in O(1) with the carry
-//     trick used for escaped characters in SIMD JSON parsers (runs of ones pair up from their first bit), so
-//     the sequencer knows token, LSP and LIP counts of the window from popcounts and gives the worker exact
-//     list offsets.
-//   * LIS pass (generation by generation = the reference's FIFO order): unfired entries and fired B entries
-//     take one bit; only a fired type-A entry (1 + 4..8 bits) shifts what follows.  Lane l precomputes the
-//     length a fired A entry would have at window position l; a scalar walk hops from fired A to fired A
-//     (find-first-set on `bits & type-mask`) and records their positions.  The worker rebuilds entry starts from
-//     that mask, lane = stream position, and produces next generation / retained list / LIP / LSP appends; the
-//     running list lengths pass from worker to worker through a small LDS chain.
+// start; everything else (values, list appends) is data parallel once that is known.
+//   * LIP pass: tokens are '0' | '1 s'.  No serial walker: every lane takes one 64-bit stream window, the token-start
+//     mask of a window is computed in O(1) for both possible carry-in states with the carry trick used for escaped
+//     characters in SIMD JSON parsers (runs of ones pair up from their first bit), the carry functions and the token /
+//     LSP / LIP counts are combined with block scans, and the windows' entries are then emitted by all wavefronts.
+//   * LIS pass (generation by generation = the reference's FIFO order): unfired entries and fired B entries take one
+//     bit; only a fired type-A entry (1 + 4..8 bits) shifts what follows.  Wavefront 0, the sequencer, hops from fired
+//     A to fired A with a hand-written scalar loop (find-first-set on `bits & type-mask`, token length by v_readlane)
+//     and publishes, per 64-bit window, the mask of fired entries through an LDS ring.  Wavefront 1, the helper, runs
+//     ahead of it and prepares each window's bits and per-position token lengths.  The other wavefronts are workers:
+//     they rebuild entry starts from the mask, lane = stream position, and produce next generation / retained list /
+//     LIP / LSP appends; the running list lengths pass from worker to worker through a small LDS chain.
 //   * refinement: bit t belongs to LSP entry t -- all wavefronts, no sequencing.
 // Decoded magnitudes live next to the LSP (lsp_val) and are scattered into the coefficient array at the end;
 // the few operations that consumed one of the last 8 bits of the stream (possible pad bits, Q9) are replayed
@@ -277,36 +276,9 @@ __device__ __forceinline__ uint32_t stream_word(const BitSrc &bs, uint32_t wi) {
     return v;
 }
 
-// 64 consecutive 64-bit stream words, one per lane: the sequencer fetches its windows with v_readlane
-// (a chunk serves 63 windows: window k also needs word k+1).  The chunk after the current one is loaded at the same
-// time and only moved into place 63 windows later, so its latency is never waited for inside a pass.
-struct RegChunk {
-    uint64_t v, vn;    // current chunk, next chunk (words base64+63 ...)
-    uint32_t base64;
-    uint32_t valid;
-};
+// 64-bit stream word `w64` (two 32-bit words), zero at and past nbits
 __device__ __forceinline__ uint64_t stream_word64(const BitSrc &bs, uint32_t w64) {
     return (uint64_t)stream_word(bs, 2 * w64) | ((uint64_t)stream_word(bs, 2 * w64 + 1) << 32);
-}
-__device__ __forceinline__ void window(const BitSrc &bs, RegChunk &rc, uint32_t widx, uint32_t lane, uint64_t &lo,
-                                       uint64_t &hi) {
-    // uniform values: say so, or the test below is compiled as divergent code on every window
-    const uint32_t rc_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.base64);
-    const uint32_t rc_valid = (uint32_t)__builtin_amdgcn_readfirstlane((int)rc.valid);
-    uint32_t k = widx - rc_base;
-    if (!rc_valid || widx < rc_base || widx + 1 >= rc_base + 64) {
-        if (rc_valid && widx == rc_base + 63) {
-            rc.v = rc.vn;  // prefetched 63 windows ago
-        } else {
-            rc.v = stream_word64(bs, widx + lane);
-        }
-        rc.base64 = widx;
-        rc.valid = 1;
-        rc.vn = stream_word64(bs, widx + 63 + lane);
-        k = 0;
-    }
-    lo = readlane64(rc.v, k);
-    hi = readlane64(rc.v, k + 1);
 }
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
@@ -729,8 +701,6 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
         uint32_t seq = 0;                    // items produced so far (kept in step by every wave at phase ends)
         uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
-        RegChunk rc;
-        rc.v = 0; rc.vn = 0; rc.base64 = 0; rc.valid = 0;
 #ifdef DEC_PROF
         uint64_t pf[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
