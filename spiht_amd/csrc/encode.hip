@@ -14,7 +14,9 @@
 // Integer/bit work, latency- and LDS-bound; no roofline claim.
 #include "common.h"
 
+#ifndef ENC_BLOCK
 #define ENC_BLOCK 1024
+#endif
 
 __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 ? -x : x); }
 
