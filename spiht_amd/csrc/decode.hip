@@ -953,8 +953,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         }
                         const uint32_t pslot = kw % DEC_PREP;
                         const uint32_t LAv = sh.plav[pslot][lane];
-                        const uint64_t lo_v = sh.plo[pslot];
-                        const uint64_t lo = (uint64_t)RFL((uint32_t)lo_v) | ((uint64_t)RFL((uint32_t)(lo_v >> 32)) << 32);
+                        const uint64_t lo_v = sh.plo[pslot];  // consumed below, after the type-mask set-up has hidden the LDS latency
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
@@ -970,6 +969,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             if (ch + 1 >= blk0 + 64) build_block(ch);
                             const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
                             uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
+                            asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
+                            const uint64_t lo = (uint64_t)RFL((uint32_t)lo_v) | ((uint64_t)RFL((uint32_t)(lo_v >> 32)) << 32);
                             uint64_t Lr = lo >> pos, c64;
                             uint32_t f, dd, len;
                             // The walk, hand-scheduled: this serial chain bounds the whole decoder and hipcc's version of
