@@ -315,7 +315,7 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
 __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, uint64_t fm, uint32_t e_start, uint32_t pos0,
-                                            uint32_t pos1, uint32_t lane) {
+                                            uint32_t pos1, uint32_t lane, uint32_t kw) {
     constexpr uint32_t HALF = DEC_RING / 2;
     const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_io);  // uniform: keep it in an SGPR
     if (seq >= DEC_RING && (seq % HALF) == 0) {
@@ -336,6 +336,8 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, uin
         // (a relaxed workgroup-scope atomic stays a ds_write; a volatile store through the generic pointer became a
         // flat_store + s_waitcnt vmcnt(0) on the sequencer's critical path)
         __hip_atomic_store(&slot->ready, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // window kw of the phase is done with the helper's ring entry: tell the helper now and then
+        if ((kw % DEC_PREP_B) == DEC_PREP_B - 1) __hip_atomic_store(&sh.sprog, kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     seq_io = seq + 1;
 }
@@ -882,7 +884,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                 const uint32_t par = phase & 1u;
                 const uint32_t seq0 = seq;  // every wave enters the phase with seq == head
                 if (wave == 0) {
-                    uint32_t i = 0, dn = 0, first = 1;
+                    uint32_t i = 0, dn = 0;
                     // Every value the walk depends on is wave-uniform; v_readfirstlane tells hipcc so (values that came
                     // from LDS or global memory are otherwise kept in VGPRs and every branch on them goes through EXEC).
 #define RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
@@ -930,6 +932,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 #define DEC_STR(x) DEC_STR2(x)
                     asm volatile(".p2align 6\n\t.fill " DEC_STR(DEC_PAD) ", 4, 0xBF800000");
 #endif
+                    if (lane == 0) {  // before the phase's first slot (same wave: LDS writes stay in order)
+                        sh.ph.seq0 = sSeq; sh.ph.widx0 = widx0s; sh.ph.b_lsp = sLsp; sh.ph.b_lip = sLip; sh.ph.b_ret = sRet;
+                    }
                     while (i < sCur) {
                         if (sP >= sNb) {
                             if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
@@ -1026,16 +1031,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                         const uint64_t tq = __builtin_amdgcn_s_memtime();
 #endif
-                        if (first && lane == 0) {  // before the phase's first slot (same wave: LDS writes stay in order)
-                            sh.ph.seq0 = sSeq; sh.ph.widx0 = widx; sh.ph.b_lsp = sLsp; sh.ph.b_lip = sLip; sh.ph.b_ret = sRet;
-                        }
-                        seq_publish(sh, sSeq, fm, i0, pos0, pos < 64u ? pos : 64u, lane);
+                        seq_publish(sh, sSeq, fm, i0, pos0, pos < 64u ? pos : 64u, lane, kw);
 #ifdef DEC_PROF
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
-                        first = 0;
-                        if ((kw % DEC_PREP_B) == DEC_PREP_B - 1 && lane == 0)  // lets the helper reuse ring entries
-                            __hip_atomic_store(&sh.sprog, kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         sP = Wb + pos;
                         if (sP > sNb) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
                     }
