@@ -314,21 +314,25 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
-__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, uint64_t fm, uint32_t e_start, uint32_t pos0,
-                                            uint32_t pos1, uint32_t lane, uint32_t kw) {
+__device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_t &fc, uint64_t fm, uint32_t e_start,
+                                            uint32_t pos0, uint32_t pos1, uint32_t lane, uint32_t kw) {
     constexpr uint32_t HALF = DEC_RING / 2;
-    const uint32_t seq = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_io);  // uniform: keep it in an SGPR
-    if (seq >= DEC_RING && (seq % HALF) == 0) {
-        const uint32_t lim = seq - HALF;  // items [0, lim) must be done
-        // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
-        const uint32_t w = lane < DEC_NWK ? lane : 0u;
-        const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
-        uint32_t spins = 0;
-        while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
+    // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of HALF
+    if (fc == 0) {
+        fc = HALF;
+        if (seq >= DEC_RING) {
+            const uint32_t lim = seq - HALF;  // items [0, lim) must be done
+            // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
+            const uint32_t w = lane < DEC_NWK ? lane : 0u;
+            const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
+            uint32_t spins = 0;
+            while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
+            }
         }
     }
+    asm volatile("s_add_i32 %0, %0, -1" : "+s"(fc) : : "scc");  // (asm: keeps the counter in an SGPR)
     if (lane == 0) {
         Slot *slot = &sh.ring[seq % DEC_RING];
         *reinterpret_cast<uint4 *>(slot) = make_uint4((uint32_t)fm, (uint32_t)(fm >> 32), e_start, pos0 | (pos1 << 8));
@@ -339,7 +343,6 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t &seq_io, uin
         // window kw of the phase is done with the helper's ring entry: tell the helper now and then
         if ((kw % DEC_PREP_B) == DEC_PREP_B - 1) __hip_atomic_store(&sh.sprog, kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    seq_io = seq + 1;
 }
 
 // worker side: the item of sequence number k (its slot has been seen ready)
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     uint32_t sP = RFL(P), sSeq = RFL(seq);
                     const uint32_t widx0s = sP >> 6;  // first window of the phase (the helper starts there too)
                     uint32_t pknown = 0;              // windows known to be prepared
+                    uint32_t sFc = (0u - sSeq) & (DEC_RING / 2 - 1);  // publishes until the next ring-space check
                     const uint32_t cur_len_v = cur_len;
                     const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
                     const uint32_t sLsp = RFL(lsp_len), sLip = RFL(lip_len), sRet = RFL(ret_len);
@@ -935,12 +939,8 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                     if (lane == 0) {  // before the phase's first slot (same wave: LDS writes stay in order)
                         sh.ph.seq0 = sSeq; sh.ph.widx0 = widx0s; sh.ph.b_lsp = sLsp; sh.ph.b_lip = sLip; sh.ph.b_ret = sRet;
                     }
-                    while (i < sCur) {
-                        if (sP >= sNb) {
-                            if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);  // waiting entry
-                            dn = 1;
-                            break;
-                        }
+                    const bool ran = i < sCur && sP < sNb;
+                    if (ran) for (;;) {
                         const uint32_t widx = sP >> 6, Wb = widx << 6, pos0 = sP & 63u;
                         uint32_t pos = pos0;
 #ifdef DEC_PROF
@@ -1031,14 +1031,26 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                         const uint64_t tq = __builtin_amdgcn_s_memtime();
 #endif
-                        seq_publish(sh, sSeq, fm, i0, pos0, pos < 64u ? pos : 64u, lane, kw);
+                        seq_publish(sh, sSeq, sFc, fm, i0, pos0, pos < 64u ? pos : 64u, lane, kw);
+                        asm volatile("s_add_i32 %0, %0, 1" : "+s"(sSeq) : : "scc");  // (asm: keeps it in an SGPR)
 #ifdef DEC_PROF
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
                         sP = Wb + pos;
-                        if (sP > sNb) { dn = 1; break; }  // the last entry's child bits run past the end of the stream
+                        // exit tests, once per window: queue exhausted or stream exhausted (the empty asm keeps hipcc from
+                        // folding the two scalar compare-and-branch pairs into six mask instructions)
+                        if (i >= sCur) break;
+                        asm volatile("");
+                        if (sP >= sNb) break;
                     }
-                    if (i < sCur) dn = 1;  // stream exhausted before the queue
+                    // the last entry's child bits ran past the end of the stream (a phase that starts at or past the end
+                    // leaves its first entry waiting, like one that reaches the end exactly)
+                    const bool over = ran && sP > sNb;
+                    if (over) dn = 1;
+                    else if (i < sCur) {  // stream exhausted before the queue: cur[i] is the entry left waiting for a bit
+                        if (META && lane == 0) tr_put(tr, sNb, (cur[i] & ENT_A) ? 2u : 5u, n, cur[i]);
+                        dn = 1;
+                    }
                     P = sP;
                     seq = sSeq;
 #undef RFL
