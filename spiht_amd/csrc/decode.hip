@@ -106,9 +106,9 @@ struct DecShared {
             Slot ring[DEC_RING];
             Chain chain[DEC_RING];
             PhaseInfo ph;
-            // helper -> sequencer: per window, the stream bits and, per window position, the length a fired type-A
-            // entry would have if it started there
-            uint64_t plo[DEC_PREP];
+            // helper -> sequencer: per window position, the length a fired type-A entry would have if it started
+            // there; zero where the stream bit is 0 (an entry cannot fire there), so the window's bits are the
+            // ballot of "non-zero" and the sequencer reads nothing else
             uint8_t plav[DEC_PREP][64];
         };
     };
@@ -116,7 +116,7 @@ struct DecShared {
     uint32_t wfun[DEC_NW];      // per-wave carry functions
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     uint32_t pprog;             // windows of this phase the helper has prepared
-    uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_PREP_B)
+    uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_RING/2 windows)
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
     uint32_t wdone[DEC_NWK];    // items completed per worker
@@ -320,6 +320,9 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_
     // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of HALF
     if (fc == 0) {
         fc = HALF;
+        // the helper's ring entries of the windows before this one are free (announced here, every HALF windows,
+        // rather than with a test of its own per window)
+        if (lane == 0) __hip_atomic_store(&sh.sprog, kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (seq >= DEC_RING) {
             const uint32_t lim = seq - HALF;  // items [0, lim) must be done
             // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
@@ -340,8 +343,6 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_
         // (a relaxed workgroup-scope atomic stays a ds_write; a volatile store through the generic pointer became a
         // flat_store + s_waitcnt vmcnt(0) on the sequencer's critical path)
         __hip_atomic_store(&slot->ready, seq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        // window kw of the phase is done with the helper's ring entry: tell the helper now and then
-        if ((kw % DEC_PREP_B) == DEC_PREP_B - 1) __hip_atomic_store(&sh.sprog, kw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -641,8 +642,7 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
                 ns += s;
             }
             const uint32_t slot = (j + u) % DEC_PREP;
-            sh.plav[slot][lane] = (uint8_t)(5 + ns);
-            if (lane == 0) sh.plo[slot] = lo;
+            sh.plav[slot][lane] = (uint8_t)((bb & 1u) ? 5 + ns : 0);  // non-zero <=> the stream bit is 1
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
@@ -958,7 +958,6 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         }
                         const uint32_t pslot = kw % DEC_PREP;
                         const uint32_t LAv = sh.plav[pslot][lane];
-                        const uint64_t lo_v = sh.plo[pslot];  // consumed below, after the type-mask set-up has hidden the LDS latency
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
@@ -975,7 +974,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
                             uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
                             asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
-                            const uint64_t lo = (uint64_t)RFL((uint32_t)lo_v) | ((uint64_t)RFL((uint32_t)(lo_v >> 32)) << 32);
+                            const uint64_t lo = __ballot(LAv != 0);  // the window's bits (see DecShared::plav)
                             uint64_t Lr = lo >> pos, c64;
                             uint32_t f, dd, len;
                             // The walk, hand-scheduled: this serial chain bounds the whole decoder and hipcc's version of
@@ -1018,8 +1017,10 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                                 : "scc");
 #undef HOP_BODY
                             // no fired type-A entry left among the window's bits: the rest take one bit each
-                            if (pos < vb) {
-                                const uint32_t z = (vb - pos) < (sCur - i - rel) ? (vb - pos) : (sCur - i - rel);
+                            {
+                                const int32_t zb = (int32_t)vb - (int32_t)pos, ze = (int32_t)(sCur - i - rel);  // ze >= 0
+                                const int32_t zm = zb < ze ? zb : ze;
+                                const uint32_t z = (uint32_t)(zm > 0 ? zm : 0);
                                 rel += z;
                                 pos += z;
                             }
@@ -1037,11 +1038,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
                         sP = Wb + pos;
-                        // exit tests, once per window: queue exhausted or stream exhausted (the empty asm keeps hipcc from
-                        // folding the two scalar compare-and-branch pairs into six mask instructions)
-                        if (i >= sCur) break;
-                        asm volatile("");
-                        if (sP >= sNb) break;
+                        // exit test, once per window: queue exhausted (i == sCur) or stream exhausted (sP >= sNb); one sign
+                        // test (all quantities are below 2^31) instead of two compare / select pairs
+                        if ((int32_t)((sCur - 1u - i) | (sNb - 1u - sP)) < 0) break;
                     }
                     // the last entry's child bits ran past the end of the stream (a phase that starts at or past the end
                     // leaves its first entry waiting, like one that reaches the end exactly)
