@@ -23,18 +23,21 @@
 #include "common.h"
 
 #ifndef DEC_NW
-#define DEC_NW 8            // wavefronts per workgroup: 1 sequencer + (DEC_NW-1) workers
+#define DEC_NW 12           // wavefronts per workgroup
 #endif
 // LIS pass roles: wavefront 0 = sequencer, wavefront 1 = helper (prepares the sequencer's per-window inputs ahead of
-// it), wavefronts 2.. = workers.  (Measured: 5 workers already keep up with the sequencer.)
+// it), wavefronts 2.. = workers.  Measured per 256 images (1080p, 0.5 bpp): 5 workers 8.6 ms, 6 workers 7.5 ms,
+// 8: 7.16 ms, 10: 7.08 ms, 14: 7.14 ms -- the all-wave passes (LIP window scan, refinement, final scatter) gain from
+// the extra waves too; keeping the sequencer's SIMD free of workers (waves 4, 8 parked) made no difference.
 #define DEC_NWK (DEC_NW - 2)
 #define DEC_WK(wave) ((wave) - 2)
 #define DEC_IS_WORKER(wave) ((wave) >= 2)
 #define DEC_PREP 64   // windows the helper may run ahead of the sequencer (ring in LDS)
 #define DEC_PREP_B 16 // ... which it announces in batches of this many
 #ifndef DEC_RING
-#define DEC_RING (8 * DEC_NW)  // windows in flight between sequencer and workers (4*NW measured 4 % slower)
+#define DEC_RING 64   // windows in flight between sequencer and workers; a power of two (32 measured 4 % slower)
 #endif
+static_assert((DEC_RING & (DEC_RING - 1)) == 0 && DEC_RING <= DEC_NW * 64, "ring: power of two, reset by one pass of the block");
 #define DEC_TAIL 16
 #define SEQ_OPEN 0xFFFFFFFFu
 #define SPIN_LIMIT (1u << 24)  // bound on every LDS spin (about a second): a protocol bug must not hang the GPU
@@ -97,9 +100,10 @@ struct LipItem {  // one LIP-pass window, produced by the parallel window scan
 
 struct DecShared {
     // The LIP pass and the LIS pass never run at the same time (barriers between them), so their scratch shares
-    // memory: 17 KB instead of 25 KB per workgroup.  That matters when this kernel runs next to the DWT kernels on
-    // another stream: 4 of their workgroups (34 KB each) + one of ours fit a CU's 160 KB, 4 + a 25 KB one do not
-    // (tools/corun_spin.py: the DWT is 23 % slower next to idle 25 KB workgroups, not at all next to 0 KB ones).
+    // memory (the LIP scratch, 32 B per window of a round, is the larger of the two: 24.6 KB at 12 wavefronts).  The
+    // footprint matters only when this kernel runs next to the DWT kernels on another stream (bench.py --pipeline 1):
+    // 4 of their workgroups (34 KB each) + 17 KB fit a CU's 160 KB, 4 + 25 KB do not (tools/corun_spin.py: the DWT is
+    // 23 % slower next to idle 25 KB workgroups, not at all next to 0 KB ones); build with -DDEC_NW=8 for that mode.
     union {
         LipItem lipq[DEC_NW * 64];
         struct {
