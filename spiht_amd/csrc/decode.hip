@@ -1123,21 +1123,37 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 
         // ---------------- scatter decoded values ----------------
         __syncthreads();
-        // four entries per thread per round, all loads before the stores: the stores may alias the lists as far as
-        // the compiler knows, so a plain loop would wait for memory once per entry
+        // Four entries per thread per batch, and the loads of the next batch are issued BEFORE the stores of this one:
+        // loads and stores retire through one in-order counter (vmcnt), so a load issued after a scattered store
+        // cannot be waited for without waiting for that store to be acknowledged (a plain loop pays load latency +
+        // store latency per batch; the stores may alias the lists as far as the compiler knows, so it keeps this order).
+        // Two register sets, alternating, so that no register move has to wait for the newest loads.
         auto scatter = [&](uint32_t t_begin, uint32_t t_end) {
-            for (uint32_t t0 = t_begin + threadIdx.x; t0 < t_end; t0 += DEC_NW * 64 * 4) {
-                int32_t v[4];
-                uint32_t ix[4];
+            constexpr uint32_t STR = DEC_NW * 64, U = 4;
+            int32_t va[U], vb[U];
+            uint32_t ia[U], ib[U];
+            auto ld = [&](uint32_t t0, int32_t(&v)[U], uint32_t(&ix)[U]) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t t = t0 + (uint32_t)u * DEC_NW * 64;
-                    v[u] = t < t_end ? lsp_val[t] : 0;
-                    ix[u] = t < t_end ? lsp_idx[t] : 0u;
+                for (uint32_t u = 0; u < U; u++) {  // unconditional loads (clamped index): no branches between them
+                    const uint32_t t = t0 + u * STR, tc = t < t_end ? t : t_end - 1u;
+                    const int32_t lv = lsp_val[tc];
+                    ix[u] = lsp_idx[tc];
+                    v[u] = t < t_end ? lv : 0;
                 }
+            };
+            auto st = [&](const int32_t(&v)[U], const uint32_t(&ix)[U]) {
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (uint32_t u = 0; u < U; u++)
                     if (v[u]) out[ix[u] & IDXM] = v[u];
+            };
+            if (t_begin >= t_end) return;
+            uint32_t t0 = t_begin + threadIdx.x;
+            ld(t0, va, ia);
+            for (; t0 < t_end; t0 += 2 * STR * U) {
+                ld(t0 + STR * U, vb, ib);
+                st(va, ia);
+                ld(t0 + 2 * STR * U, va, ia);
+                st(vb, ib);
             }
         };
         scatter(cut, lsp_len);
@@ -1182,7 +1198,19 @@ __global__ __launch_bounds__(256) void k_unscatter(DecArgs a) {
     const uint32_t cnt = a.lsp_count[slot];
     const uint32_t *idx = a.lsp_idx + (size_t)slot * a.caps.lsp;
     int32_t *out = a.out + (size_t)slot * a.g.n;
-    for (uint32_t t = part * 256u + threadIdx.x; t < cnt; t += UNSC_BLOCKS * 256u) out[idx[t] & ENT_IDX] = 0;
+    // eight loads in flight per thread, then the eight stores (a plain loop waits for memory once per entry: the
+    // store may alias the list as far as the compiler knows)
+    for (uint32_t t0 = part * 256u + threadIdx.x; t0 < cnt; t0 += UNSC_BLOCKS * 256u * 8u) {
+        uint32_t ix[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) {
+            const uint32_t t = t0 + u * UNSC_BLOCKS * 256u;
+            ix[u] = t < cnt ? idx[t] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++)
+            if (ix[u] != 0xFFFFFFFFu) out[ix[u] & ENT_IDX] = 0;
+    }
 }
 
 extern "C" int spiht_launch_unscatter(const DecArgs *a, hipStream_t st) {
