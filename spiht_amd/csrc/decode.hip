@@ -933,7 +933,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         if (lane >= nch) TAv = 0;
                         blk0 = c0;
                     };
+#ifdef DEC_PROF
+                    { const uint64_t tb = __builtin_amdgcn_s_memtime(); build_block(0); pf[1] += __builtin_amdgcn_s_memtime() - tb; pf[10] += 1; }
+#else
                     build_block(0);
+#endif
 #ifdef DEC_PAD  // set by the Makefile (tools/hop_align.py): s_nop padding, run once per phase, that puts the hop loop
                 // below 16 bytes into a 32-byte fetch block (5 % between the best and the worst offset, measured)
 #define DEC_STR2(x) #x
@@ -974,7 +978,11 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                         uint32_t rel = 0;
                         {
                             const uint32_t ch = i >> 6, r0 = i & 63u;
+#ifdef DEC_PROF
+                            if (ch + 1 >= blk0 + 64) { const uint64_t tb = __builtin_amdgcn_s_memtime(); build_block(ch); pf[1] += __builtin_amdgcn_s_memtime() - tb; pf[10] += 1; }
+#else
                             if (ch + 1 >= blk0 + 64) build_block(ch);
+#endif
                             const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
                             uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
                             asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
@@ -1123,6 +1131,7 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 
         // ---------------- scatter decoded values ----------------
         __syncthreads();
+        PF_ADD(7);
         // Four entries per thread per batch, and the loads of the next batch are issued BEFORE the stores of this one:
         // loads and stores retire through one in-order counter (vmcnt), so a load issued after a scattered store
         // cannot be waited for without waiting for that store to be acknowledged (a plain loop pays load latency +

@@ -49,7 +49,7 @@ words = (C.c_uint32 * 64)()
 L.spiht_debug_words.argtypes = [vp, vp]
 _lib.check(L.spiht_debug_words(ctx.handle, words))
 w = list(words)[16:30]
-names = ["lip_seq", "lip_wait", "lis_seq", "lis_wait", "refine", "items_lip", "items_lis", "other", "generations", "scatter", "hops", "lis_publish", "lis_window", "lis_hops"]
+names = ["lip_seq", "lis_blocks", "lis_seq", "lis_wait", "refine", "items_lip", "items_lis", "other", "generations", "scatter", "blocks", "lis_publish", "lis_window", "lis_hops"]
 tot = sum(w[k] for k in (0, 1, 2, 3, 4, 7, 9))
 for k, nm in enumerate(names):
     if k in (5, 6, 8, 10):
