@@ -993,20 +993,20 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
                             // it is more than twice as long (uniform conditions routed through VCC/EXEC).  Relative
                             // coordinates keep the dependent chain short: L = bits from the current position on, T = type
                             // mask from the current entry on, so a candidate is `L & T` (s_and sets SCC), its offset
-                            // d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (two shifts each: a single shift count
-                            // must stay below 64).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and, about 100
+                            // d = ff1, and one hop is  T >>= d+1,  L >>= d+len  (L in two shifts: a single shift count must
+                            // stay below 64; T in one: d+1 = 64 shifts by 0 instead, but then L, which had its only candidate
+                            // at bit 63, is 0 after its own shifts, the walk ends and T is not looked at again).  Chain per hop: and -> ff1 -> add -> readlane -> lshr -> and, about 100
                             // cycles (tools/ubench/hop.hip); four hops per trip save three of four taken branches.
                             // Four SALU instructions separate the s_add that makes the lane select from v_readlane.
 #define HOP_BODY                                                \
     "s_ff1_i32_b64 %[d], %[c]\n\t"                              \
     "s_add_i32 %[f], %[pos], %[d]\n\t"                          \
-    "s_lshr_b64 %[T], %[T], %[d]\n\t"                           \
     "s_lshr_b64 %[L], %[L], %[d]\n\t"                           \
+    "s_add_i32 %[d], %[d], 1\n\t"                               \
     "s_bitset1_b64 %[fm], %[f]\n\t"                             \
-    "s_lshr_b64 %[T], %[T], 1\n\t"                              \
+    "s_lshr_b64 %[T], %[T], %[d]\n\t"                           \
     "v_readlane_b32 %[len], %[LAv], %[f]\n\t"                   \
     "s_add_i32 %[rel], %[rel], %[d]\n\t"                        \
-    "s_add_i32 %[rel], %[rel], 1\n\t"                           \
     "s_lshr_b64 %[L], %[L], %[len]\n\t"                         \
     "s_add_i32 %[pos], %[f], %[len]\n\t"                        \
     "s_and_b64 %[c], %[L], %[T]\n\t"
