@@ -24,7 +24,10 @@
 #include "common.h"
 #include <stdlib.h>
 
-#define DW_TH 16      // output rows per tile
+#ifndef DW_TH
+#define DW_TH 12      // output rows per tile.  Level 1 of 256 1080p images: 12 rows 3.8-3.95 ms, 16 rows 4.05-4.2, 14: 4.1,
+#endif                // 10: 4.4, 20: 4.5, 24: 4.2 (25.9 KB of LDS per workgroup at 12 rows: six workgroups per CU)
+#define DW32_TH 16    // ... of the single-precision kernel (12 rows: 3.9 instead of 2.85 ms)
 #define DW_TW 64      // output cols per tile
 #define DW_BLOCK 256
 
@@ -80,9 +83,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NR = 2 * DW_TH + F - 2;  // input rows needed
     constexpr int HC = (NC + 1) / 2;       // columns per parity plane
     static_assert(NC <= DW_BLOCK, "one thread per input column");
-    // two column-parity planes; the +8 makes the plane stride an odd multiple of 16 banks, so the even and odd lanes
-    // of one ds_write_b64 lane group land on different banks
-    constexpr int RS = HC + 1, PS = DW_TH * RS + 8;
+    // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
+    // lanes of one ds_write_b64 lane group land on different banks
+    constexpr int RS = HC + 1, PS = DW_TH * RS + (24 - (DW_TH * RS) % 16) % 16;  // PS % 16 == 8
     __shared__ double s_lo[2][PS];
     __shared__ double s_hi[2][PS];
     __shared__ int s_row[NR];
@@ -131,11 +134,11 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
     uint32_t amax = 0;
 #pragma unroll
-    for (int u = 0; u < DW_TH * DW_TW / DW_BLOCK; u++) {
+    for (int u = 0; u < (DW_TH * DW_TW + DW_BLOCK - 1) / DW_BLOCK; u++) {
         const int p = tid + u * DW_BLOCK;
         const int o = p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
-        if (oh >= a.out_h || ow >= a.out_w) continue;
+        if (o >= DW_TH || oh >= a.out_h || ow >= a.out_w) continue;
         // x~ index 2*ow+1-j  ->  tile column 2*wcol + F-1-j  ->  parity (F-1-j)&1, half-column wcol + (F-1-j)/2
         double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
 #pragma unroll
@@ -180,17 +183,17 @@ __device__ __forceinline__ int32_t quant_f32(float v, double m, double q, float 
 
 template <int F, uint32_t LOM, uint32_t HIM>
 __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
-    constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
+    constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW32_TH + F - 2, HC = (NC + 1) / 2;
     static_assert(NC <= DW_BLOCK, "one thread per input column");
-    constexpr int RS = HC + 1, PS = DW_TH * RS + 8;
+    constexpr int RS = HC + 1, PS = DW32_TH * RS + 8;
     __shared__ float s_lo[2][PS];
     __shared__ float s_hi[2][PS];
     __shared__ int s_row[NR];
     __shared__ float s_flo[F], s_fhi[F];  // float copies of the filters, for the run-time-ordered overhang sums
     uint32_t tbx, tby, tbz;
-    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW32_TH - 1) / DW32_TH, a.planes, tbx, tby, tbz);
     const int plane = (int)tbz;
-    const int oh0 = (int)tby * DW_TH, ow0 = (int)tbx * DW_TW;
+    const int oh0 = (int)tby * DW32_TH, ow0 = (int)tbx * DW_TW;
     const float *__restrict__ in = reinterpret_cast<const float *>(a.in) + (size_t)plane * a.in_h * a.in_w;
     const int tid = threadIdx.x;
     float flo[F], fhi[F];
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
         }
         const int par = tid & 1, hc = tid >> 1;
 #pragma unroll
-        for (int o = 0; o < DW_TH; o++) {
+        for (int o = 0; o < DW32_TH; o++) {
             float sl = 0.0f, shh = 0.0f;
             const int i = 2 * (oh0 + o) + 1;
             if (i < a.in_h || a.mode == 4) {  // (constant-edge mode: pywt keeps ascending order over the overhang too)
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
     float *__restrict__ llo = a.last ? nullptr : reinterpret_cast<float *>(a.ll_out) + (size_t)plane * a.out_h * a.out_w;
     uint32_t amax = 0;
 #pragma unroll
-    for (int u = 0; u < DW_TH * DW_TW / DW_BLOCK; u++) {
+    for (int u = 0; u < DW32_TH * DW_TW / DW_BLOCK; u++) {
         const int p = tid + u * DW_BLOCK;
         const int o = p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
@@ -438,9 +441,9 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // ------------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------------
-#define IW_TH 32    // output rows per tile (two halves of 16, one per half of the workgroup; a multiple of 4).  28 rows
-                    // (34 KB of LDS instead of 38, so that four tiles fit a CU next to a list-coder workgroup of another
-                    // stream) was tried: 3 % slower alone and no faster when overlapped
+#ifndef IW_TH
+#define IW_TH 16    // output rows per tile (two halves of 8, one per half of the workgroup; a multiple of 4).  Level 1 of 256
+#endif              // 1080p images: 16 rows 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67, 8: 4.74
 #define IW_TW 128   // output cols per tile, one thread per column per half
 
 __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
@@ -565,7 +568,7 @@ template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
     if (a.f32) {
-        uint32_t ntf = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+        uint32_t ntf = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW32_TH - 1) / DW32_TH) * (uint32_t)planes;
         hipLaunchKernelGGL((k_dwt_level_f32<F, LOM, HIM>), dim3(ntf), dim3(DW_BLOCK), 0, st, a);
         return (int)hipGetLastError();
     }
