@@ -1201,7 +1201,9 @@ __global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
 // Puts back the zeros: clears exactly the cells the decoder wrote (its LSP lists are still in the slot scratch), so a
 // coefficient array that is only ever used as decoder output and inverse-transform input never needs a full zero-fill
 // again.  One image per slot (B <= nslots).
+#ifndef UNSC_BLOCKS
 #define UNSC_BLOCKS 8
+#endif
 __global__ __launch_bounds__(256) void k_unscatter(DecArgs a) {
     const uint32_t slot = blockIdx.x / UNSC_BLOCKS, part = blockIdx.x % UNSC_BLOCKS;
     const uint32_t cnt = a.lsp_count[slot];
