@@ -28,7 +28,9 @@
 #define DW_TH 12      // output rows per tile.  Level 1 of 256 1080p images: 12 rows 3.8-3.95 ms, 16 rows 4.05-4.2, 14: 4.1,
 #endif                // 10: 4.4, 20: 4.5, 24: 4.2 (25.9 KB of LDS per workgroup at 12 rows: six workgroups per CU)
 #define DW32_TH 16    // ... of the single-precision kernel (12 rows: 3.9 instead of 2.85 ms)
+#ifndef DW_TW
 #define DW_TW 64      // output cols per tile
+#endif
 #define DW_BLOCK 256
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Remap the linear block id so
