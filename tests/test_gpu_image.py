@@ -338,3 +338,31 @@ def test_random_images_settings_and_budgets(oracle):
         dec = spiht_amd.decode_image(enc, s)
         ref = oracle.decode_image(ref_bytes, ref_n, c, H, W, wv, level, q, mults)
         assert np.array_equal(dec, ref), tag
+
+
+@pytest.mark.gpu
+def test_cli_encode_save_load_decode(tmp_path, oracle):
+    """`python -m spiht_amd.encode_decode` (reference: encode_decode.py:17-90): file in, file out, and the saved
+    container decodes to the same picture; the stream equals the oracle's for the same settings."""
+    pytest.importorskip("PIL")
+    import spiht_amd
+    from spiht_amd import utils
+    from spiht_amd.encode_decode import build_parser, main
+    img = np.round(synth_image(77, 3, 120, 200) * 255) / 255
+    utils.imsave(tmp_path / "in.png", img)
+    args = build_parser().parse_args([str(tmp_path / "in.png"), "--bpp", "0.5", "--color_model", "RGB",
+                                      "--per_channel_quant_scales", "1., 1., 1.", "--out", str(tmp_path / "out.png"),
+                                      "--save", str(tmp_path / "e.spiht")])
+    enc, dec = main(args)
+    assert (enc.h, enc.w, enc.c, enc.level) == (120, 200, 3, 3) and len(enc.encoded_bytes) == (round(0.5 * 120 * 200) + 7) // 8
+    assert dec.shape == (3, 120, 200) and float(((img - dec) ** 2).mean()) < 1e-2
+    s = spiht_amd.SpihtSettings(quantization_scale=255.0, color_model="RGB", per_channel_quant_scales=[1.0, 1.0, 1.0])
+    ref_bytes, ref_n, _ = _oracle_roundtrip(oracle, utils.imload(tmp_path / "in.png"), s, 3, round(0.5 * 120 * 200))
+    assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n
+    out = utils.imload(tmp_path / "out.png")
+    assert out.shape == (3, 120, 200)
+    args2 = build_parser().parse_args([str(tmp_path / "in.png"), "--color_model", "RGB", "--per_channel_quant_scales",
+                                       "1., 1., 1.", "--out", str(tmp_path / "out2.png"), "--load", str(tmp_path / "e.spiht")])
+    enc2, dec2 = main(args2)
+    assert enc2 == enc and np.array_equal(dec2, dec)
+    assert np.array_equal(utils.imload(tmp_path / "out2.png"), out)
