@@ -47,8 +47,8 @@ def synth_image(seed, c, h, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--cpu-sample", type=int, default=24,
@@ -57,13 +57,14 @@ def main():
                     help="pixel dtype.  float64 (default) is what the reference's loader produces and what the metric is quoted "
                          "on; float32 runs the single-precision forward transform PyWavelets would run on such pixels (half the "
                          "DWT read traffic); the decode side is float64 either way, as in the reference")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: steps are software-pipelined over two contexts -- the HBM-bound halves (DWT + pyramid of step "
-                         "i+1, inverse DWT of step i-1) run while the list coder works on step i "
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="1 (default): steps are software-pipelined -- the HBM-bound halves (DWT + pyramid of step i+1, "
+                         "inverse DWT of step i-1) run on one context while step i is list-coded on another "
                          "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  Measured: "
-                         "22.2 vs 24.5 ms/step (+10 %% images/s), but co-running kernels slow each other (list decoder "
-                         "x1.5-1.8, DWT x1.4: tools/corun.py), so the DWT's own roofline fraction drops from 0.62 to 0.54.  "
-                         "0 (default): every step runs its stages back to back on one stream, each kernel with the whole GPU")
+                         "19.1-20.0 vs 22.5-22.9 ms/step.  Kernels that run side by side slow each other (inverse DWT "
+                         "x1.6, decoder x1.25, forward DWT x1.05), so per-kernel times and the roofline fraction reported "
+                         "here are those of the shared GPU.  0: every step runs its stages back to back on one stream, each "
+                         "kernel with the whole GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -140,14 +141,16 @@ def main():
         # context L list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).
         from spiht_amd.batch import OverlappedCodec
         pipe = OverlappedCodec(codec, B)
-        ctxs.append(pipe.L)
+        ctxs.extend(pipe.Ls)
         gather_hook = None
         if dist is not None:
-            # the stream gather rides on L's stream between the encoder's and the decoder's list kernels
-            l_stream = torch.cuda.ExternalStream(pipe.L.stream_ptr(), device=torch.device("cuda", local_rank))
+            # the stream gather rides on the batch's list-coding stream between the encoder's and the
+            # decoder's list kernels
+            l_streams = {cx.handle.value: torch.cuda.ExternalStream(cx.stream_ptr(), device=torch.device("cuda", local_rank))
+                         for cx in pipe.Ls}
 
-            def gather_hook(_ctx_l):
-                with torch.cuda.stream(l_stream):
+            def gather_hook(ctx_l):
+                with torch.cuda.stream(l_streams[ctx_l.handle.value]):
                     dist.all_gather_into_tensor(gathered, out_t)
                     dist.all_gather_into_tensor(g_nbits, nbits_t)
                     dist.all_gather_into_tensor(g_maxn, maxn_t)
@@ -258,6 +261,25 @@ def main():
             t_dec.append((t3 - t2) * 1e3)
         single = {"encode_ms": round(sorted(t_enc)[2], 3), "decode_ms": round(sorted(t_dec)[2], 3)}
 
+        # the same kernels with the GPU to themselves (one serial round trip of the batch after the timed region): in
+        # the pipelined schedule the numbers above are those of kernels that share the GPU with the list coder
+        alone = None
+        if pipe is not None:
+            ctx.synchronize()
+            ctx.reset_timing()
+            ctx.set_timing(True)
+            for _ in range(2):
+                enc_chunk(0)
+                dec_chunk(0)
+            ctx.synchronize()
+            ctx.set_timing(False)
+            tm = ctx.timing()
+            a_ms = {k2: v2[0] / v2[1] for k2, v2 in tm.items() if v2[1] and k2 in ("dwt_level1", "idwt_level1")}
+            if "dwt_level1" in a_ms:
+                alone = {"dwt_level1_ms": round(a_ms["dwt_level1"], 4),
+                         "dwt_level1_frac": round(dwt_bytes / (a_ms["dwt_level1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "idwt_level1_ms": round(a_ms.get("idwt_level1", float("nan")), 4)}
+
         # the other HBM-bound passes north_star names, same definition (algorithmic bytes / stage time per launch group)
         def _gbs(stage, nbytes):
             ms, n = stages.get(stage, (0.0, 0))
@@ -290,14 +312,15 @@ def main():
             "config": {"workload": "cfg2 image (1920x1080 RGB, bior2.2 reflect level 7, q=50, 0.5 bpp) x %d per GPU "
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
                        "images_per_gpu": B, "streams": K, "images_per_launch": per_launch,
-                       "schedule": ("steps software-pipelined over two contexts: HBM-bound passes of steps i+1 / i-1 run "
-                                    "while step i is list-coded" if pipe is not None else "stages back to back"), "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
+                       "schedule": ("steps software-pipelined: HBM-bound passes of steps i+1 / i-1 on one stream while step i is "
+                                    "list-coded on another" if pipe is not None else "stages back to back"), "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]]},
             "roofline": {"bound": "hbm", "kernel": ("k_dwt_level<6>" if pix == np.float64 else "k_dwt_level_f32<6>") +
                          " (forward DWT level 1, fused quantise)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4)},
+                         "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4),
+                         "kernel_alone": alone},
             "stages_ms_per_step_summed_over_streams": {k: round(v[0] / args.steps, 3) for k, v in stages.items() if v[1]},
             "roofline_other_hbm_passes": other,
             "single_image_latency": single,

@@ -198,6 +198,12 @@ int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64
  *   spiht_encode_lists_batch_i32  coefficients + pyramid -> streams                  (back half; = k_encode)
  *   spiht_decode_lists_batch_i32  streams -> coefficients; d_out must be ZERO-FILLED by the caller (spiht_dev_memset)
  *   spiht_dequant_idwt_batch_f64  coefficients -> pixels                             (above)
+ *   spiht_unscatter_lists_batch_i32  after the inverse transform has read d_out: puts back the zeros in exactly the
+ *                                 cells the context's last spiht_decode_lists_batch_i32 wrote (through the decoder's
+ *                                 lists), so the array is zero again for the next decode without a full zero-fill;
+ *                                 falls back to the zero-fill when another list-coding call on the context came in
+ *                                 between.  (The reference allocates a fresh zero array per call,
+ *                                 encoder_decoder.rs:308; this keeps one array zero instead.)
  * Results are identical to the fused entry points. */
 int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
                                 int wavelet, int mode, int level, double q_scale, const double *channel_mults,
@@ -209,6 +215,7 @@ int spiht_encode_lists_batch_i32(spiht_ctx *ctx, const int32_t *d_x, const uint8
 int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
                                  const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
                                  int64_t ll_w, int32_t *d_out_zeroed);
+int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w);
 
 /* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
  * counts the decoder takes, without a host round trip. */

@@ -35,7 +35,7 @@ SYMBOLS = [
     "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
     "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_event_create", "spiht_event_destroy", "spiht_event_record",
     "spiht_ctx_wait_event", "spiht_ctx_stream", "spiht_dwt_pyramid_batch_f64", "spiht_encode_lists_batch_i32",
-    "spiht_decode_lists_batch_i32", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
+    "spiht_decode_lists_batch_i32", "spiht_unscatter_lists_batch_i32", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
     "spiht_ctx_stage_name", "spiht_ctx_get_timing", "spiht_encode_i32", "spiht_encode_bound", "spiht_decode_i32",
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
@@ -78,6 +78,7 @@ def lib():
         L.spiht_dwt_pyramid_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]
         L.spiht_encode_lists_batch_i32.argtypes = [vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, u64, vp, u64, vp, vp]
         L.spiht_decode_lists_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
+        L.spiht_unscatter_lists_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64]
         L.spiht_ctx_set_timing.argtypes = [vp, i32]
         L.spiht_ctx_reset_timing.argtypes = [vp]
         L.spiht_ctx_stage_name.restype = C.c_char_p

@@ -148,26 +148,30 @@ class BatchCodec:
 
 
 class OverlappedCodec:
-    """Round trips a sequence of batches with the two kinds of work on two contexts.
+    """Round trips a sequence of batches with the two kinds of work on different contexts.
 
-    The transform / pyramid / zero-fill / inverse-transform passes are HBM-bound; the list coder is latency-bound and
-    leaves the HBM idle.  Context H runs the former, context L the latter, ordered with events only (the host never
-    blocks), so while L list-codes batch i, H already transforms batch i+1 and inverse-transforms batch i-1:
+    The transform / pyramid / inverse-transform passes are HBM-bound; the list coder is latency-bound and leaves the
+    HBM idle.  Context H runs the former, contexts L0 / L1 (alternating by batch) the latter, ordered with events only
+    (the host never blocks), so while a batch is list-coded, H already transforms the next one and inverse-transforms
+    the previous one:
 
-        H:  A(i) Z(i)              [D(i-1) done] I(i-1)   A(i+1) Z(i+1)            [D(i) done] I(i) ...
-        L:        [A(i),Z(i) done] E(i) D(i)                       [A(i+1) done]   E(i+1) D(i+1) ...
+        H:  A(i)               [X(i-1) done] I(i-1)   A(i+1)                 [X(i) done] I(i) ...
+        L:  [I(i-2) done] U(i-2)   [A(i) done] E(i) X(i)      [I(i-1) done] U(i-1)   [A(i+1) done] E(i+1) X(i+1) ...
 
-    A = DWT + quantise + pyramid, Z = zero the coefficient array the decoder scatters into, E/D = encoder / decoder
-    list kernels, I = dequantise + inverse DWT.  HBM-bound kernels never overlap one another (one in-order stream), so
-    each still sees the whole HBM.  Results are bit-identical to BatchCodec's fused calls (same kernels).
-    Coefficient arrays, pyramid and decoder output are double-buffered; streams are not (E(i+1) follows D(i) on L).
-    `between` (optional callable) runs between E(i) and D(i) with L's stream: the hook for the stream gather of a
-    multi-GPU job."""
+    A = DWT + quantise + pyramid, E / X = encoder / decoder list kernels, I = dequantise + inverse DWT, U = put the
+    zeros back into the coefficient array X(i-2) scattered into (spiht_unscatter_lists_batch_i32: through the
+    decoder's lists, which is why each of the two arrays has its own list-coding context) -- a full zero-fill per
+    batch would add 6.6 GB of writes to the HBM-bound side.  E(i+1) is ordered after X(i), so list kernels never run
+    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).  Results are
+    bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder output are
+    double-buffered.  `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook
+    for the stream gather of a multi-GPU job."""
 
     def __init__(self, codec, B, ctx_l=None):
         self.codec, self.B = codec, int(B)
         self.H = codec.ctx
-        self.L = ctx_l if ctx_l is not None else _lib.Context(self.H.device)
+        self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device), _lib.Context(self.H.device)]
+        self.L = self.Ls[0]
         g = codec.geom
         n = codec.c * g["enc_h"] * g["enc_w"]
         self.n = n
@@ -175,10 +179,18 @@ class OverlappedCodec:
         self.coeffs, self.rec = mk((B, n), np.int32), mk((B, n), np.int32)
         self.dmsb, self.lmsb = mk((B, n), np.uint8), mk((B, n), np.uint8)
         self.maxabs = mk((B,), np.uint32)
-        self.ev_a = [_lib.Event(self.H) for _ in range(2)]
-        self.ev_d = [_lib.Event(self.L) for _ in range(2)]
+        for r in self.rec:  # zero once; from then on U keeps them zero
+            self.H.memset(r.ptr, 0, r.nbytes)
+        self.H.synchronize()
+        self.ev_a = [_lib.Event(self.H) for _ in range(2)]    # A(i) done
+        self.ev_d = [_lib.Event(self.Ls[s]) for s in range(2)]  # X(i) done
+        self.ev_i = [_lib.Event(self.H) for _ in range(2)]    # I(i) done
+        self.used = [False, False]
         self.i = 0
         self._pending = None  # (slot, d_img_out) of the batch whose inverse transform has not been queued yet
+
+    def contexts(self):
+        return [self.H] + self.Ls
 
     def _idwt(self, s, d_img_out):
         cd = self.codec
@@ -186,33 +198,43 @@ class OverlappedCodec:
         _lib.check(cd.L.spiht_dequant_idwt_batch_f64(
             self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
             float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
+        self.H.record(self.ev_i[s])
 
     def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None):
         """queue the round trip of one batch (device pointers as in BatchCodec.encode_device / decode_device)"""
         cd, B, g = self.codec, self.B, self.codec.geom
         s = self.i & 1
+        Lc = self.Ls[s]
         vp = C.c_void_p
         q = float(cd.settings.quantization_scale)
-        # H: front half of the encoder, and the zero-fill the decoder needs
+        # H: front half of the encoder
         _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
             self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
             vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
-        self.H.memset(self.rec[s].ptr, 0, self.rec[s].nbytes)
         self.H.record(self.ev_a[s])
-        # L: list coding
-        self.L.wait_event(self.ev_a[s])
+        # L: zeros back into the array batch i-2 was decoded into, once its inverse transform (queued on H by the
+        # previous submit) has read it ...
+        if self.used[s]:
+            Lc.wait_event(self.ev_i[s])
+            _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
+        # ... and list coding, after the previous batch's decoder on the other context
+        if self.used[s ^ 1]:
+            Lc.wait_event(self.ev_d[s ^ 1])
+        Lc.wait_event(self.ev_a[s])
         _lib.check(cd.L.spiht_encode_lists_batch_i32(
-            self.L.handle, vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr), B,
+            Lc.handle, vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr), B,
             cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], cd.max_bits, vp(d_out), cd.slot_stride, vp(d_nbits),
             vp(d_max_n)))
         if between is not None:
-            between(self.L)
-        _lib.check(cd.L.spiht_nbits_to_nbytes(self.L.handle, vp(d_nbits), B, vp(d_nbytes)))
+            between(Lc)
+        _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(d_nbits), B, vp(d_nbytes)))
         _lib.check(cd.L.spiht_decode_lists_batch_i32(
-            self.L.handle, vp(d_out), cd.slot_stride, vp(d_nbytes), vp(d_max_n), B, cd.c, g["enc_h"], g["enc_w"],
+            Lc.handle, vp(d_out), cd.slot_stride, vp(d_nbytes), vp(d_max_n), B, cd.c, g["enc_h"], g["enc_w"],
             g["ll_h"], g["ll_w"], vp(self.rec[s].ptr)))
-        self.L.record(self.ev_d[s])
-        # H: back half of the previous batch's decoder
+        Lc.record(self.ev_d[s])
+        self.used[s] = True
+        # H: back half of the previous batch's decoder.  (Ordering X(i) after I(i-1) instead, so that the inverse
+        # transform runs alone, was measured: the forward DWT then runs beside the decoder and takes twice as long.)
         if self._pending is not None:
             self._idwt(*self._pending)
         self._pending = (s, d_img_out)
@@ -226,5 +248,6 @@ class OverlappedCodec:
 
     def synchronize(self):
         self.flush()
-        self.L.synchronize()
+        for Lc in self.Ls:
+            Lc.synchronize()
         self.H.synchronize()

@@ -83,6 +83,9 @@ struct spiht_ctx {
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
+    // spiht_decode_lists_batch_i32 -> spiht_unscatter_lists_batch_i32: the launch whose scatter can still be undone
+    DecArgs last_dec;
+    bool last_dec_valid = false;
     // timing
     bool timing = false;
     struct Rec { int stage; hipEvent_t a, b; };
@@ -378,6 +381,7 @@ extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
     int st = read_err(ctx);  // includes the stream synchronize
     if (st != SPIHT_OK) {
         ctx->recz_clean = false;  // a guard tripped: the decoder's lists may not describe what it wrote
+        ctx->last_dec_valid = false;
         (void)clear_err(ctx);
         (void)hipStreamSynchronize(ctx->stream);
     }
@@ -461,6 +465,7 @@ static int alloc_lists(spiht_ctx *ctx, const ListCaps &caps, int want_slots, boo
     size_t s_lip = align256((size_t)caps.lip * 4 * slots), s_lsp = align256((size_t)caps.lsp * 4 * slots),
            s_lis = align256((size_t)caps.lis * 4 * slots);
     size_t total = 2 * s_lip + (decoder ? 2 : 1) * s_lsp + 3 * s_lis;
+    ctx->last_dec_valid = false;  // the lists get a new user
     CHK(ensure(ctx, ctx->lists, total));
     char *base = (char *)ctx->lists.p;
     p->lip0 = (uint32_t *)base; base += s_lip;
@@ -1224,7 +1229,30 @@ extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_dat
     if (B == 0) return SPIHT_OK;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false));
+    DecArgs da;
+    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false, &da));
+    ctx->last_dec = da;
+    ctx->last_dec_valid = da.nslots >= (int)B;  // otherwise slots were reused inside the launch
+    return SPIHT_OK;
+}
+
+// Puts the zeros back into the array the context's last spiht_decode_lists_batch_i32 scattered into (after its
+// consumer, the inverse transform, has read it): clears exactly the cells that call wrote, through the decoder's
+// lists, instead of a zero-fill of B*c*h*w*4 bytes before the next decode.  Falls back to that zero-fill when the
+// lists are gone (another list-coding call on this context in between, slots reused within the launch, a latched
+// device error).  Queued on the context's stream like everything else.
+extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w) {
+    if (!ctx || !d_out || B < 0 || c < 1 || h < 1 || w < 1) return SPIHT_ERR_ARG;
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    StageTimer t(ctx, ST_MEMSET);
+    const DecArgs &da = ctx->last_dec;
+    if (ctx->last_dec_valid && da.out == d_out && da.B == (int)B && (int64_t)da.g.n == c * h * w) {
+        LAUNCHCHK(spiht_launch_unscatter(&da, ctx->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * (size_t)(c * h * w) * 4, ctx->stream));
+    }
     return SPIHT_OK;
 }
 

@@ -38,6 +38,9 @@
 #define DEC_RING 64   // windows in flight between sequencer and workers; a power of two (32 measured 4 % slower)
 #endif
 static_assert((DEC_RING & (DEC_RING - 1)) == 0 && DEC_RING <= DEC_NW * 64, "ring: power of two, reset by one pass of the block");
+#ifndef DEC_WSLEEP
+#define DEC_WSLEEP 1  // s_sleep argument (x64 cycles) of a worker waiting for its next window
+#endif
 #define DEC_TAIL 16
 #define SEQ_OPEN 0xFFFFFFFFu
 #define SPIN_LIMIT (1u << 24)  // bound on every LDS spin (about a second): a protocol bug must not hang the GPU
@@ -603,7 +606,7 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
             }
             const uint32_t pe = lds_load(&sh.phase_end[par]);
             if (pe != SEQ_OPEN && pe <= myk) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(DEC_WSLEEP);
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
         }
         if (!got) break;
@@ -666,7 +669,12 @@ __device__ __forceinline__ void seq_close(DecShared &sh, uint32_t par, uint32_t 
 }
 
 template <bool META>
-__global__ __launch_bounds__(DEC_NW * 64) void k_decode(DecArgs a) {
+#ifndef DEC_WAVES_PER_EU
+#define DEC_WAVES_PER_EU 5  // caps the kernel at 96 VGPRs (35 spilled, none on the sequencer's path: same speed alone,
+#endif                      // 6.95 ms) so that three DWT wavefronts per SIMD fit beside a resident decoder workgroup when
+                            // the two run on different streams (bench.py --pipeline 1: 19.6 instead of 22.5 ms per step)
+__global__ __launch_bounds__(DEC_NW * 64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES_PER_EU, DEC_WAVES_PER_EU)))
+void k_decode(DecArgs a) {
     __shared__ DecShared sh;
     constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
     const Geom g = a.g;
