@@ -61,10 +61,10 @@ def main():
                     help="1 (default): steps are software-pipelined -- the HBM-bound halves (DWT + pyramid of step i+1, "
                          "inverse DWT of step i-1) run on one context while step i is list-coded on another "
                          "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  Measured: "
-                         "19.1-20.0 vs 22.5-22.9 ms/step.  Kernels that run side by side slow each other (inverse DWT "
-                         "x1.6, decoder x1.25, forward DWT x1.05), so per-kernel times and the roofline fraction reported "
-                         "here are those of the shared GPU.  0: every step runs its stages back to back on one stream, each "
-                         "kernel with the whole GPU")
+                         "19.4-19.6 vs 22.6-22.9 ms/step.  The forward DWT starts when the decoder of the previous step "
+                         "has finished, so it still has the GPU to itself (same time as in the serial schedule); the "
+                         "inverse DWT and the decoder share it (x1.9 and x1.25 their own time).  0: every step runs its "
+                         "stages back to back on one stream, each kernel with the whole GPU")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -265,10 +265,12 @@ def main():
         # the pipelined schedule the numbers above are those of kernels that share the GPU with the list coder
         alone = None
         if pipe is not None:
+            enc_chunk(0)
+            dec_chunk(0)
             ctx.synchronize()
             ctx.reset_timing()
             ctx.set_timing(True)
-            for _ in range(2):
+            for _ in range(3):
                 enc_chunk(0)
                 dec_chunk(0)
             ctx.synchronize()

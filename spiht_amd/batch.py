@@ -156,7 +156,7 @@ class OverlappedCodec:
     the previous one:
 
         H:  A(i)               [X(i-1) done] I(i-1)   A(i+1)                 [X(i) done] I(i) ...
-        L:  [I(i-2) done] U(i-2)   [A(i) done] E(i) X(i)      [I(i-1) done] U(i-1)   [A(i+1) done] E(i+1) X(i+1) ...
+        L:  [A(i), I(i-2) done] U(i-2) E(i) X(i)              [A(i+1), I(i-1) done] U(i-1) E(i+1) X(i+1) ...
 
     A = DWT + quantise + pyramid, E / X = encoder / decoder list kernels, I = dequantise + inverse DWT, U = put the
     zeros back into the coefficient array X(i-2) scattered into (spiht_unscatter_lists_batch_i32: through the
@@ -214,13 +214,15 @@ class OverlappedCodec:
         self.H.record(self.ev_a[s])
         # L: zeros back into the array batch i-2 was decoded into, once its inverse transform (queued on H by the
         # previous submit) has read it ...
+        # (queued behind A(i): right after I(i-2) the forward DWT of this batch starts on H, and the scattered writes
+        # would take HBM bandwidth from it; here they run beside the next inverse transform instead)
+        if self.used[s ^ 1]:
+            Lc.wait_event(self.ev_d[s ^ 1])
+        Lc.wait_event(self.ev_a[s])
         if self.used[s]:
             Lc.wait_event(self.ev_i[s])
             _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
         # ... and list coding, after the previous batch's decoder on the other context
-        if self.used[s ^ 1]:
-            Lc.wait_event(self.ev_d[s ^ 1])
-        Lc.wait_event(self.ev_a[s])
         _lib.check(cd.L.spiht_encode_lists_batch_i32(
             Lc.handle, vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr), B,
             cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], cd.max_bits, vp(d_out), cd.slot_stride, vp(d_nbits),
