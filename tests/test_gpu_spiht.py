@@ -205,3 +205,54 @@ def test_random_geometries_and_budgets(oracle):
             raise AssertionError("case %d: c=%d h=%d w=%d ll=%dx%d kind=%d max_bits=%d max|x|=%d: %r"
                                  % (done, c, h, w, lh, lw, kind, mb, int(np.abs(x).max()), e))
         done += 1
+
+
+def test_unscatter_lists_puts_the_zeros_back(oracle):
+    """spiht_unscatter_lists_batch_i32 (include/spiht_hip.h, "two halves"): after it the decoder's output array is
+    all zero again -- through the decoder's lists when they still exist, by zero-fill when another list-coding call
+    used the context in between -- and the next decode into the same array is exact."""
+    import ctypes as C
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    L = _lib.lib()
+    ctx = _lib.Context(0)
+    vp = C.c_void_p
+    B, c, h, w, lh, lw, mb = 3, 2, 40, 56, 5, 7, 6000
+    xs = np.stack([synth_coeffs(900 + b, c, h, w, lh, lw) for b in range(B)])
+    n = c * h * w
+    d_x, d_rec = DeviceArray(ctx, (B, n), np.int32), DeviceArray(ctx, (B, n), np.int32)
+    d_dm, d_lm, d_ma = DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B,), np.uint32)
+    slot = ((mb + 7) // 8 + 3) & ~3
+    d_out, d_nb, d_mn, d_ny = (DeviceArray(ctx, (B, slot), np.uint8), DeviceArray(ctx, (B,), np.uint64),
+                               DeviceArray(ctx, (B,), np.uint8), DeviceArray(ctx, (B,), np.uint64))
+    d_x.upload(xs.reshape(B, n))
+
+    def encode():
+        _lib.check(L.spiht_pyramid_batch_i32(ctx.handle, vp(d_x.ptr), B, c, h, w, lh, lw, vp(d_dm.ptr), vp(d_lm.ptr), vp(d_ma.ptr)))
+        _lib.check(L.spiht_encode_lists_batch_i32(ctx.handle, vp(d_x.ptr), vp(d_dm.ptr), vp(d_lm.ptr), vp(d_ma.ptr), B, c, h, w,
+                                                  lh, lw, mb, vp(d_out.ptr), slot, vp(d_nb.ptr), vp(d_mn.ptr)))
+        _lib.check(L.spiht_nbits_to_nbytes(ctx.handle, vp(d_nb.ptr), B, vp(d_ny.ptr)))
+
+    def decode():
+        _lib.check(L.spiht_decode_lists_batch_i32(ctx.handle, vp(d_out.ptr), slot, vp(d_ny.ptr), vp(d_mn.ptr), B, c, h, w, lh, lw,
+                                                  vp(d_rec.ptr)))
+
+    def unscatter():
+        _lib.check(L.spiht_unscatter_lists_batch_i32(ctx.handle, vp(d_rec.ptr), B, c, h, w))
+
+    ctx.memset(d_rec.ptr, 0, d_rec.nbytes)
+    encode()
+    ref = []
+    for b in range(B):
+        d, mn, nbits = oracle.encode_nbits(xs[b], lh, lw, mb)
+        ref.append(oracle.decode(d, mn, c, h, w, lh, lw).reshape(-1))
+    ref = np.stack(ref)
+    for between in (False, True, False):
+        decode()
+        ctx.synchronize()
+        assert np.array_equal(d_rec.download(), ref)
+        if between:
+            encode()  # the lists now belong to the encoder: the call has to fall back to a zero-fill
+        unscatter()
+        ctx.synchronize()
+        assert not d_rec.download().any()
