@@ -125,7 +125,12 @@ __device__ __forceinline__ int start_plane(uint32_t maxabs, const float *thr) {
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_encode(EncArgs a) {
+#ifndef ENC_WAVES_PER_EU
+#define ENC_WAVES_PER_EU 6  // caps the kernel at 80 VGPRs (5 spilled; same speed alone): beside a resident encoder
+#endif                      // workgroup (16 wavefronts) three instead of two DWT wavefronts per SIMD fit -- 19.5 instead
+                            // of 19.75 ms per pipelined step.  64 VGPRs: the encoder itself takes 4.7 instead of 2.7 ms
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(ENC_WAVES_PER_EU, ENC_WAVES_PER_EU)))
+void k_encode(EncArgs a) {
     __shared__ EncShared<BLOCK> sh;
     const Geom g = a.g;
     const uint32_t tid = threadIdx.x;
