@@ -187,14 +187,17 @@ int spiht_encode_image_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, 
 
 /* Significance pyramid on its own (device pointers), for parity tests and profiling:
  * d_x int32 [B,c,h,w] -> d_dmsb, d_lmsb uint8 [B,c,h,w] (1 + msb of the D / L set maxima of the node with
- * that index, 0 = empty/zero; only nodes with offspring are written) and d_maxabs uint32 [B]. */
+ * that index, 0 = empty/zero; only nodes with offspring are written) and d_maxabs uint32 [B] (NULL: not computed). */
 int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
                             int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs);
 
 /* The two halves of each direction on their own (device pointers, asynchronous).  The transform + pyramid half is
  * HBM-bound, the list-coding half is latency-bound and leaves the HBM idle, so a caller that keeps several batches in
  * flight runs them on two contexts ordered with events (bench.py):
- *   spiht_dwt_pyramid_batch_f64   pixels -> coefficients + D/L pyramid + max|coef|   (front half of encode_image)
+ *   spiht_dwt_pyramid_batch_f64   pixels -> coefficients + D/L pyramid + max|coef|   (front half of encode_image);
+ *                                 with d_dmsb = d_lmsb = NULL the pyramid is left out and can be queued on another
+ *                                 context with spiht_pyramid_batch_i32(..., d_maxabs = NULL) (NULL: max|coef| is
+ *                                 already known, no pass over the coefficients for it)
  *   spiht_encode_lists_batch_i32  coefficients + pyramid -> streams                  (back half; = k_encode)
  *   spiht_decode_lists_batch_i32  streams -> coefficients; d_out must be ZERO-FILLED by the caller (spiht_dev_memset)
  *   spiht_dequant_idwt_batch_f64  coefficients -> pixels                             (above)

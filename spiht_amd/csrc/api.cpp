@@ -826,14 +826,14 @@ extern "C" int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uin
 extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_t B, int64_t c, int64_t h, int64_t w,
                                        int64_t ll_h, int64_t ll_w, uint8_t *d_dmsb, uint8_t *d_lmsb,
                                        uint32_t *d_maxabs) {
-    if (!ctx || !d_x || !d_dmsb || !d_lmsb || !d_maxabs || B < 0) return SPIHT_ERR_ARG;
+    if (!ctx || !d_x || !d_dmsb || !d_lmsb || B < 0) return SPIHT_ERR_ARG;
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
     if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    {
+    if (d_maxabs) {  // null: the caller has max|x| already (spiht_dwt_pyramid_batch_f64 without the pyramid)
         StageTimer t(ctx, ST_ABSMAX);
         LAUNCHCHK(spiht_launch_absmax(d_x, (int)B, g.n, d_maxabs, ctx->stream));
     }
@@ -1165,7 +1165,7 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
 extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
                                            int wavelet, int mode, int level, double q_scale, const double *channel_mults,
                                            int32_t *d_coeffs, uint8_t *d_dmsb, uint8_t *d_lmsb, uint32_t *d_maxabs) {
-    if (!ctx || !d_img || !d_coeffs || !d_dmsb || !d_lmsb || !d_maxabs) return SPIHT_ERR_ARG;
+    if (!ctx || !d_img || !d_coeffs || !d_maxabs || (!d_dmsb) != (!d_lmsb)) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
@@ -1183,6 +1183,7 @@ extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, 
         int32_t *co = d_coeffs + (size_t)b0 * g.n;
         CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
                         d_maxabs + b0));
+        if (!d_dmsb) continue;  // transform + max|coefficient| only: the pyramid is queued elsewhere (spiht_pyramid_batch_i32)
         StageTimer t(ctx, ST_PYRAMID);
         LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, ctx->stream));
     }
