@@ -366,3 +366,38 @@ def test_cli_encode_save_load_decode(tmp_path, oracle):
     enc2, dec2 = main(args2)
     assert enc2 == enc and np.array_equal(dec2, dec)
     assert np.array_equal(utils.imload(tmp_path / "out2.png"), out)
+
+
+@pytest.mark.gpu
+def test_transform_and_pyramid_queued_separately():
+    """include/spiht_hip.h "two halves": spiht_dwt_pyramid_batch_f64 without the pyramid + spiht_pyramid_batch_i32 without
+    the max pass give what the fused call gives"""
+    import ctypes as C
+    from spiht_amd import _lib
+    from spiht_amd.batch import BatchCodec, DeviceArray
+    from spiht_amd.spiht_wrapper import SpihtSettings
+    L, vp = _lib.lib(), C.c_void_p
+    ctx = _lib.Context(0)
+    B, c, H, W = 2, 3, 70, 90
+    cd = BatchCodec(c, H, W, SpihtSettings(), None, 5000, ctx=ctx)
+    g = cd.geom
+    n = c * g["enc_h"] * g["enc_w"]
+    d_img = DeviceArray(ctx, (B, c, H, W), np.float64)
+    d_img.upload(np.stack([synth_image(31 + b, c, H, W) for b in range(B)]))
+    outs = []
+    for split in (False, True):
+        co, dm, lm, ma = (DeviceArray(ctx, (B, n), np.int32), DeviceArray(ctx, (B, n), np.uint8),
+                          DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B,), np.uint32))
+        for a in (co, dm, lm, ma):
+            ctx.memset(a.ptr, 0, a.nbytes)
+        q = float(cd.settings.quantization_scale)
+        _lib.check(L.spiht_dwt_pyramid_batch_f64(ctx.handle, vp(d_img.ptr), B, c, H, W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
+                                                 vp(co.ptr), vp(None if split else dm.ptr), vp(None if split else lm.ptr), vp(ma.ptr)))
+        if split:
+            _lib.check(L.spiht_pyramid_batch_i32(ctx.handle, vp(co.ptr), B, c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"],
+                                                 vp(dm.ptr), vp(lm.ptr), vp(None)))
+        ctx.synchronize()
+        outs.append([a.download() for a in (co, dm, lm, ma)])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
+    assert outs[0][3].all() and outs[0][1].any()
