@@ -102,17 +102,23 @@ def test_inverse_matches_pywt_goldens_and_oracle(oracle):
     (1, 1, 65, 33, "haar", "periodic", 3, 50.0, None),
     (1, 2, 40, 40, "bior2.2", "zero", 0, 50.0, [2.0, 0.5]),          # level 0: quantise only
     (1, 1, 9, 300, "bior2.2", "constant", 1, 50.0, None),
+    # many planes (batches): odd sizes with the trim rule, long filter, per-channel scales
+    (50, 3, 72, 100, "bior2.2", "reflect", 4, 50.0, None),
+    (43, 3, 1080 // 2, 1920 // 2, "bior2.2", "reflect", 6, 50.0, None),
+    (129, 1, 61, 47, "bior4.4", "symmetric", 3, 255.0, None),
+    (44, 3, 96, 96, "bior6.8", "reflect", 3, 20.0, [3.0, 1.0, 0.5]),
 ])
 def test_forward_inverse_vs_oracle(oracle, cfg):
     B, c, H, W, wavelet, mode, level, q, mults = cfg
     imgs = np.stack([synth_image(1000 + b, c, H, W) for b in range(B)])
     got = _gpu_dwt(imgs, wavelet, mode, level, q, mults)
-    for b in range(B):
+    check = range(B) if B <= 8 else sorted({0, 1, B // 2, B - 2, B - 1})  # many planes: the oracle checks a few images
+    for b in check:
         arr, g = oracle.wavedec2_array(imgs[b], wavelet, mode, level)
         ref = oracle.quantize(arr, q, mults)
         assert np.array_equal(got[b], ref), (cfg, int((got[b] != ref).sum()))
     back = _gpu_idwt(got, H, W, wavelet, mode, level, q, mults)
-    for b in range(B):
+    for b in check:
         ref = oracle.waverec2_array(oracle.dequantize(got[b], q, mults), H, W, wavelet, level)
         assert back[b].shape == ref.shape
         assert np.array_equal(back[b], ref), (cfg, float(np.abs(back[b] - ref).max()))
