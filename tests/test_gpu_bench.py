@@ -1,0 +1,37 @@
+"""bench.py prints the one JSON line the driver reads: keys, types and the internal checks, on a small batch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("pipeline", [1, 0])
+def test_bench_line_contract(pipeline):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "6", "--distinct", "3", "--cpu-sample", "1", "--pipeline", str(pipeline)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mpixels/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert abs(d["value"] - 6 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    assert "workload" in d["config"] and d["config"]["images_per_gpu"] == 6 and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
+    assert (r["kernel_alone"] is not None) == bool(pipeline)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and "sample" in c
+    chk = d["check"]
+    assert chk["nbits_all_equal_budget"] and chk["stream_bit_exact_vs_oracle"] and chk["decoded_image_bit_exact_vs_oracle"]
