@@ -947,7 +947,7 @@ void k_decode(DecArgs a) {
                     build_block(0);
 #endif
 #ifdef DEC_PAD  // set by the Makefile (tools/hop_align.py): s_nop padding, run once per phase, that puts the hop loop
-                // below 16 bytes into a 32-byte fetch block (5 % between the best and the worst offset, measured)
+                // at the offset in a 32-byte fetch block that was measured best (4 % between the best and the worst offset)
 #define DEC_STR2(x) #x
 #define DEC_STR(x) DEC_STR2(x)
                     asm volatile(".p2align 6\n\t.fill " DEC_STR(DEC_PAD) ", 4, 0xBF800000");

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Build helper (spiht_amd/csrc/Makefile): how many s_nop to put in front of the decoder's window loop so that the
-hand-written hop loop of k_decode<false> starts 20 bytes into a 32-byte block -- measured best on MI355X (decode of 256
-images, four hops per loop trip: 8.39 ms at offset 20, 8.46 at 12, 8.65 at 8; with two hops per trip the spread was
-8.53 ... 8.99 ms).  Input: decode.hip compiled for the device only with
--DDEC_PAD=0.  Prints the pad count (0 if anything goes wrong: the build then just keeps whatever alignment it has)."""
+hand-written hop loop of k_decode<false> starts 16 bytes into a 32-byte block -- measured best on MI355X with the
+11-instruction hop body, four hops per loop trip (decode of 256 images by offset: 16: 6.98 ms, 8: 7.07, 20: 7.10,
+0: 7.13, 28: 7.17, 24: 7.18, 4: 7.24, 12: 7.25; with the earlier 12-instruction body the best offset was 20).
+Input: decode.hip compiled for the device only with -DDEC_PAD=0.  Prints the pad count (0 if anything goes wrong: the
+build then just keeps whatever alignment it has)."""
 import re
 import subprocess
 import sys
@@ -21,6 +22,6 @@ try:
     addrs = [int(m.group(1), 16) for m in re.finditer(r"s_ff1_i32_b64 .*// ([0-9A-Fa-f]+):", dis)]
     BODIES = 4         # hop bodies per loop trip (decode.hip)
     label = addrs[-BODIES]  # the first one of the last group is the loop label
-    print(((20 - label) % 32) // 4)
+    print(((16 - label) % 32) // 4)
 except Exception:
     print(0)
