@@ -44,6 +44,18 @@ def synth_image(seed, c, h, w):
     return np.round(np.clip(b, 0, 1) * 255).astype(np.uint8) / 255
 
 
+def _cpu_worker(job):
+    """one oracle round trip in a worker process (cpu_baseline_all_cores); returns pixels coded"""
+    seed, reps = job
+    from oracle import oracle as O
+    img = synth_image(seed, C_IMG, H, W)
+    mb = int(H * W * BPP)
+    for _ in range(reps):
+        data, mn, _g = O.encode_image(img, WAVELET, MODE, LEVEL, QSCALE, None, mb)
+        O.decode_image(data, mn, C_IMG, H, W, WAVELET, LEVEL, QSCALE, None)
+    return reps * H * W
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,6 +65,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic images cycled through the batch")
     ap.add_argument("--cpu-sample", type=int, default=24,
                     help="images the CPU baseline codes, cycling through the distinct ones (0 = skip); 24 = about 11 s of one core")
+    ap.add_argument("--cpu-cores", type=int, default=16,
+                    help="processes of the all-cores CPU figure (one image each; 16 = the CPU share of a one-GPU box; <= 1: skip)")
     ap.add_argument("--pixels", choices=["float64", "float32"], default="float64",
                     help="pixel dtype.  float64 (default) is what the reference's loader produces and what the metric is quoted "
                          "on; float32 runs the single-precision forward transform PyWavelets would run on such pixels (half the "
@@ -349,6 +363,20 @@ def main():
                 "kind": "port",
                 "sample": "%d of the same 1080p images, encode %.2fs + decode %.2fs, oracle/liboracle.so (gcc -O3), "
                           "host has %d cores" % (ns, t_enc, t_dec, os.cpu_count() or 0)}
+            # the same port, one independent image per core (the reference is single-threaded per image; SURVEY.md 8d ii)
+            if args.cpu_cores > 1:
+                import concurrent.futures as cf
+                import multiprocessing as mp
+                ncores = min(args.cpu_cores, os.cpu_count() or 1)
+                jobs = [(1000 + i % nd, 2) for i in range(ncores)]
+                with cf.ProcessPoolExecutor(max_workers=ncores, mp_context=mp.get_context("spawn")) as ex:
+                    list(ex.map(_cpu_worker, [(1000, 1)] * ncores))  # start-up (imports, library load) outside the timing
+                    tc = time.perf_counter()
+                    npx = sum(ex.map(_cpu_worker, jobs))
+                    t_all = time.perf_counter() - tc
+                result["cpu_baseline_all_cores"] = {
+                    "value": round(npx / t_all / 1e6, 3), "unit": "Mpixels/s", "cores": ncores, "kind": "port",
+                    "sample": "%d processes x 2 round trips of a 1080p image in %.2fs" % (ncores, t_all)}
             # bit-exactness of the timed GPU output against the oracle, image 0 of rank 0
             out0 = np.empty(slot, np.uint8)
             ctx.download(out0, out_ptr)
