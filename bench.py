@@ -345,7 +345,8 @@ def main():
         }
 
         # ---- CPU baseline: the oracle (port of the reference algorithm) on a bounded sample, one core ----
-        if args.cpu_sample > 0:
+        result["cpu_baseline"] = None
+        if args.cpu_sample > 0 and world == 1:  # the CPU leg runs at N = 1 only
             from oracle import oracle as O
             ns = args.cpu_sample
             tc = time.perf_counter()
