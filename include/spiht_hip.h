@@ -220,6 +220,13 @@ int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t
                                  int64_t ll_w, int32_t *d_out_zeroed);
 int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w);
 
+/* Colour model change on the device (the reference converts on the host through colour-science, color_models.py:6-13,
+ * called from spiht_wrapper.py:158-160 and :278-279): B three-channel float64 images [B,3,npix]; per pixel
+ * w = M * spow(A * u, p) with spow(x, p) = sign(x)|x|^p -- RGB -> IPT is (XYZ->LMS * RGB->XYZ, 0.43, LMS->IPT), the way
+ * back the inverses with 1/0.43.  A, M: row-major 3x3 host arrays.  d_out may equal d_in.  Asynchronous. */
+int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, int64_t B, int64_t npix, const double *A,
+                           const double *M, double p);
+
 /* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
  * counts the decoder takes, without a host round trip. */
 int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes);

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import _lib
+from . import _lib, color_models
 from .spiht_wrapper import EncodingResult, SpihtSettings, _geometry, _mults_arg, _wavelet_mode_ids
 
 
@@ -52,8 +52,10 @@ class DeviceArray:
 class BatchCodec:
     """encode/decode B images [B,c,H,W] (float64) at a fixed bit budget.
 
-    settings / level / max_bits have the meaning of spiht_wrapper.encode_image; colour conversion is not
-    applied here (convert before uploading)."""
+    settings / level / max_bits have the meaning of spiht_wrapper.encode_image.  The host-array calls (encode,
+    decode, decode_prefixes) apply settings.color_model on the device (color_models.device_convert, an elementwise
+    kernel before the transform / after the inverse transform); the raw device-pointer calls take and return pixels
+    in the coded colour model."""
 
     def __init__(self, c, H, W, settings=None, level=None, max_bits=None, ctx=None, pixel_dtype=np.float64):
         # pixel_dtype float32: the encoder side runs PyWavelets' single-precision arithmetic (what the reference does
@@ -104,6 +106,12 @@ class BatchCodec:
         d_maxn = DeviceArray(ctx, (B,), np.uint8)
         try:
             d_img.upload(images)
+            if self.settings.color_model is not None:  # wrapper:158-160
+                if self.pixel_dtype != np.float64:
+                    raise ValueError("colour conversion on the device takes float64 pixels")
+                if self.c != 3:
+                    raise ValueError("colour conversion needs 3 channels")
+                color_models.device_convert(ctx, d_img.ptr, B, self.H * self.W, 'RGB', self.settings.color_model)
             self.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
             ctx.synchronize()
             out, nbits, maxn = d_out.download(), d_nbits.download(), d_maxn.download()
@@ -132,6 +140,11 @@ class BatchCodec:
             d_nbytes.upload(nbytes)
             d_maxn.upload(maxn)
             self.decode_device(d_data.ptr, d_nbytes.ptr, d_maxn.ptr, B, d_img.ptr, slot_stride=stride)
+            if self.settings.color_model is not None:  # wrapper:278-279
+                if self.c != 3:
+                    raise ValueError("colour conversion needs 3 channels")
+                color_models.device_convert(ctx, d_img.ptr, B, self.geom["rec_h"] * self.geom["rec_w"],
+                                            self.settings.color_model, 'RGB')
             ctx.synchronize()
             return d_img.download()
         finally:

@@ -49,3 +49,25 @@ def convert(im, src, dest):
         raise ValueError("colour conversion needs 3 channels")
     out = _rgb_to_ipt(im) if (src, dest) == ("RGB", "IPT") else _ipt_to_rgb(im)
     return np.moveaxis(out, -1, 0)
+
+
+
+def device_convert(ctx, d_ptr, B, npix, src, dest):
+    """The same conversion on the GPU, in place, for B images [B,3,npix] (float64) at device pointer d_ptr: one
+    elementwise kernel on the context's stream (spiht_color3_batch_f64).  Same matrices as above; the power function is
+    the device library's, so results agree with convert() to a few ulp, not bit for bit."""
+    import ctypes as C
+    from . import _lib
+    if src not in SUPPORTED_MODELS:
+        raise ValueError(f'{src} is not a supported color model. Supported models are {SUPPORTED_MODELS}')
+    if dest not in SUPPORTED_MODELS:
+        raise ValueError(f'{dest} is not a supported color model. Supported models are {SUPPORTED_MODELS}')
+    if src == dest:
+        return
+    if (src, dest) == ("RGB", "IPT"):
+        A, M, p = _XYZ2LMS @ _RGB2XYZ, _LMS2IPT, 0.43
+    else:
+        A, M, p = np.linalg.inv(_LMS2IPT), np.linalg.inv(_XYZ2LMS @ _RGB2XYZ), 1.0 / 0.43
+    A, M = np.ascontiguousarray(A, np.float64), np.ascontiguousarray(M, np.float64)
+    _lib.check(_lib.lib().spiht_color3_batch_f64(ctx.handle, C.c_void_p(d_ptr), C.c_void_p(d_ptr), int(B), int(npix),
+                                                 C.c_void_p(A.ctypes.data), C.c_void_p(M.ctypes.data), float(p)))

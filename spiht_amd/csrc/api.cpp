@@ -25,6 +25,8 @@ int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes);
 int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                           void *temp, size_t temp_bytes, hipStream_t st);
 int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st);
+int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
+                        hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
@@ -1254,6 +1256,18 @@ extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, i
     } else {
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * (size_t)(c * h * w) * 4, ctx->stream));
     }
+    return SPIHT_OK;
+}
+
+// Colour model change of B three-channel float64 images [B,3,npix] on the device: per pixel w = M * spow(A * u, p) with
+// spow(x, p) = sign(x)|x|^p (the RGB <-> IPT shape; A, M row-major 3x3 host arrays).  d_out may equal d_in.
+extern "C" int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, int64_t B, int64_t npix,
+                                      const double *A, const double *M, double p) {
+    if (!ctx || !d_in || !d_out || !A || !M || B < 0 || npix < 1 || B > 65535) return SPIHT_ERR_ARG;
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    LAUNCHCHK(spiht_launch_color3(d_in, d_out, (int)B, (size_t)npix, A, M, p, ctx->stream));
     return SPIHT_OK;
 }
 
