@@ -312,6 +312,17 @@ def main():
             # significance pyramid: read 4 B per coefficient, write 1 B per parent (D) + 1 B per grand-parent (L)
             "pyramid": _gbs("pyramid", per_launch * (4 * n_coef + n_par + n_par // 4)),
         }
+        # PMC traffic of those two passes (tools/collect_traffic.py), per image, beside the algorithmic bytes
+        opath = os.path.join(ROOT, "profiles", "hbm_traffic_other.json")
+        if os.path.exists(opath) and pix == np.float64:
+            try:
+                ot = json.load(open(opath))
+                for key, src in (("idwt_level1", "idwt_level1"), ("pyramid", "pyramid_rounds")):
+                    if other.get(key) is not None:
+                        other[key]["traffic_bytes_per_image"] = round(ot[src]["hbm_bytes_per_image"])
+                        other[key]["algorithmic_bytes_per_image"] = ot[src]["algorithmic_bytes_per_image"]
+            except Exception:
+                pass
         result = {
             "metric": "Mpixels/sec encode+decode at fixed bpp; bitstream-exact vs Rust ref",
             "value": round(mpix, 2),

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""HBM traffic of the forward-DWT level-1 kernel from rocprofv3 PMC counters -> profiles/dwt_l1_traffic.json.
+"""HBM traffic of the HBM-bound kernels from rocprofv3 PMC counters -> profiles/dwt_l1_traffic.json (the forward level-1
+kernel, read by bench.py) and profiles/hbm_traffic_other.json (inverse level 1, pyramid rounds).
 
-Run on the GPU box (two separate --pmc passes, as MI355X_MICROARCH.md prescribes):
+Run on the GPU box (separate --pmc passes per counter, as MI355X_MICROARCH.md prescribes):
     python tools/collect_traffic.py [batch]
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream, so the read
 side is doubled before comparing with byte counts."""
@@ -15,27 +16,54 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-out = {"images_per_launch": B}
-for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-    d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp")
-    subprocess.check_call(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-                           "python3", os.path.join(ROOT, "tools", "prof_stage.py"), "dwt", str(B), "2"],
-                          cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    best = {}
-    for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(p)):
-            if "k_dwt_level" in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                gs = int(r["Grid_Size"])
-                best.setdefault(gs, []).append(float(r["Counter_Value"]))
-    gs = max(best)  # the level-1 launch has the largest grid
-    out[counter + "_KiB_raw"] = sum(best[gs]) / len(best[gs])
-out["read_bytes"] = out["FETCH_SIZE_KiB_raw"] * 1024 * 2  # gfx950: FETCH_SIZE counts 64 B per 128 B request
-out["write_bytes"] = out["WRITE_SIZE_KiB_raw"] * 1024
-out["hbm_bytes_per_launch"] = out["read_bytes"] + out["write_bytes"]
-out["hbm_bytes_per_image"] = out["hbm_bytes_per_launch"] / B
-out["algorithmic_bytes_per_image"] = 3 * (1080 * 1920 * 8 + 542 * 962 * 20)
+ITERS = 2
+
+
+def counters(stage, kernel):
+    """per counter: {grid size: mean counter value per launch} of the launches of `kernel` in a run of `stage`"""
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        subprocess.check_call(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                               "python3", os.path.join(ROOT, "tools", "prof_stage.py"), stage, str(B), str(ITERS)],
+                              cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        by = {}
+        for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(p)):
+                if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    by.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+        res[counter] = {g: sum(v) / len(v) for g, v in by.items()}
+    return res
+
+
+def bytes_of(c, grids):
+    rd = sum(c["FETCH_SIZE"][g] for g in grids) * 1024 * 2  # gfx950: FETCH_SIZE counts 64 B per 128 B request
+    wr = sum(c["WRITE_SIZE"][g] for g in grids) * 1024
+    return rd, wr
+
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-for dst in (os.path.join(ROOT, "gpurun_out", "dwt_l1_traffic.json"),):
-    json.dump(out, open(dst, "w"), indent=1)
+# forward level 1: the largest grid of k_dwt_level
+c = counters("dwt", "k_dwt_level")
+g1 = max(c["FETCH_SIZE"])
+rd, wr = bytes_of(c, [g1])
+out = {"images_per_launch": B, "FETCH_SIZE_KiB_raw": c["FETCH_SIZE"][g1], "WRITE_SIZE_KiB_raw": c["WRITE_SIZE"][g1],
+       "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_image": (rd + wr) / B,
+       "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dwt_l1_traffic.json"), "w"), indent=1)
 print(json.dumps(out))
+# inverse level 1 (largest grid of k_idwt_level) and the pyramid (all rounds of k_pyr_round + k_pyr_ll are small)
+other = {"images_per_launch": B}
+c = counters("idwt", "k_idwt_level")
+g1 = max(c["FETCH_SIZE"])
+rd, wr = bytes_of(c, [g1])
+other["idwt_level1"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
+                        "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
+c = counters("pyramid", "k_pyr_round")
+rd, wr = bytes_of(c, list(c["FETCH_SIZE"]))
+n_coef, n_par = 3 * 1111 * 1949, 3 * (1111 // 2) * (1949 // 2)
+other["pyramid_rounds"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
+                           "algorithmic_bytes_per_image": 4 * n_coef + n_par + n_par // 4}
+json.dump(other, open(os.path.join(ROOT, "gpurun_out", "hbm_traffic_other.json"), "w"), indent=1)
+print(json.dumps(other))
