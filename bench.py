@@ -312,6 +312,11 @@ def main():
             # significance pyramid: read 4 B per coefficient, write 1 B per parent (D) + 1 B per grand-parent (L)
             "pyramid": _gbs("pyramid", per_launch * (4 * n_coef + n_par + n_par // 4)),
         }
+        if alone is not None and other.get("idwt_level1") is not None and alone["idwt_level1_ms"] == alone["idwt_level1_ms"]:
+            # in the pipelined schedule the inverse transform shares the GPU with the list decoder (by design)
+            nb_i = per_launch * C_IMG * (H * W * 8 + h1 * w1 * 8 + 3 * h1 * w1 * 4)
+            other["idwt_level1"]["alone_ms"] = alone["idwt_level1_ms"]
+            other["idwt_level1"]["alone_frac"] = round(nb_i / (alone["idwt_level1_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         # PMC traffic of those two passes (tools/collect_traffic.py), per image, beside the algorithmic bytes
         opath = os.path.join(ROOT, "profiles", "hbm_traffic_other.json")
         if os.path.exists(opath) and pix == np.float64:
