@@ -242,18 +242,19 @@ def test_raw_batch_entry_points(oracle):
     ctx.synchronize()  # the error word was cleared
 
 
-def test_overlapped_codec_matches_fused(oracle):
+@pytest.mark.parametrize("shape", [(3, 96, 136, 5, 9000, 7), (1, 61, 47, 1, 2500, 5), (3, 130, 75, 3, None, 4),
+                                   (2, 200, 264, 9, 40000, 6)])
+def test_overlapped_codec_matches_fused(oracle, shape):
     """split entry points + events (include/spiht_hip.h "two halves"): same streams, same images as the fused calls,
     over several pipelined batches with different contents"""
     from spiht_amd import _lib
     from spiht_amd.batch import BatchCodec, DeviceArray, OverlappedCodec
     from spiht_amd.spiht_wrapper import SpihtSettings
-    c, H, W, B = 3, 96, 136, 5
-    ctx = _lib.default_context()
-    codec = BatchCodec(c, H, W, SpihtSettings(), None, 9000, ctx=ctx)
+    c, H, W, B, mb, steps = shape  # steps: the buffer pairs are reused -- the zeros put back after a batch are what the
+    ctx = _lib.default_context()   # next one on the same pair needs
+    codec = BatchCodec(c, H, W, SpihtSettings(), None, mb, ctx=ctx)
     g = codec.geom
     ov = OverlappedCodec(codec, B)
-    steps = 7  # every buffer pair is reused three times: the zeros put back after a batch are what the next one needs
     imgs = [np.stack([synth_image(100 * s + b, c, H, W) for b in range(B)]) for s in range(steps)]
     d_imgs = [DeviceArray(ctx, (B, c, H, W), np.float64) for _ in range(steps)]
     d_recs = [DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64) for _ in range(steps)]
