@@ -231,12 +231,57 @@ int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, in
  * counts the decoder takes, without a host round trip. */
 int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes);
 
+/* The drop-in calls on HOST arrays, one C call each (what spiht_amd.encode_image / decode_image / decode_from_rec_arr
+ * bind): replace encode_image (spiht_wrapper.py:142-189: wavedec2 -> coeffs_to_array -> channel scales -> quantize ->
+ * spiht.encode), decode_image (:192-216, :259-276: spiht.decode -> dequantize -> waverec2) and decode_from_rec_arr
+ * (:259-276) without the colour step.  img: [c,H,W] C-contiguous; out / out_cap as in spiht_encode_i32; img_out:
+ * float64 [c, rec_H, rec_W] (spiht_geometry).  Pixels, coefficients and stream stay in the context's grow-only device
+ * buffers: no device allocation per call once a size has been seen.  Synchronous. */
+int spiht_encode_image_host_f64(spiht_ctx *ctx, const double *img, int64_t c, int64_t H, int64_t W, int wavelet,
+                                int mode, int level, double q_scale, const double *channel_mults, uint64_t max_bits,
+                                uint8_t *out, uint64_t out_cap, uint64_t *out_nbits, uint8_t *max_n);
+int spiht_encode_image_host_f32(spiht_ctx *ctx, const float *img, int64_t c, int64_t H, int64_t W, int wavelet,
+                                int mode, int level, double q_scale, const double *channel_mults, uint64_t max_bits,
+                                uint8_t *out, uint64_t out_cap, uint64_t *out_nbits, uint8_t *max_n);
+int spiht_decode_image_host_f64(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t H,
+                                int64_t W, int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                double *img_out);
+int spiht_dequant_idwt_host_f64(spiht_ctx *ctx, const int32_t *rec, int64_t c, int64_t H, int64_t W, int wavelet, int mode,
+                                int level, double q_scale, const double *channel_mults, double *img_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU: one process per GPU, every rank codes its own images (the reference's encode / decode
+ * are pure functions of one image, src/lib.rs:24-42 -- nothing is exchanged while coding); the ONE exchange of the
+ * path is the gather of the finished streams.  It runs on RCCL (ncclAllGather over xGMI), inside this library, on
+ * the context's stream; librccl is loaded on first use.
+ * ------------------------------------------------------------------------------------- */
+typedef struct spiht_comm spiht_comm;
+#define SPIHT_COMM_ID_BYTES 128
+/* Rank 0 makes the job's id (ncclGetUniqueId) and hands its 128 bytes to every rank by any host channel
+ * (spiht_amd/dist.py: a TCP exchange on MASTER_ADDR). */
+int spiht_comm_unique_id(uint8_t *id128);
+/* Collective over all ranks: joins the communicator of `world` ranks as `rank`, on the context's GPU. */
+int spiht_comm_create(spiht_ctx *ctx, const uint8_t *id128, int world, int rank, spiht_comm **out);
+void spiht_comm_destroy(spiht_comm *comm);
+int spiht_comm_info(spiht_comm *comm, int *world, int *rank, int *rccl_version);
+/* All-gather of B stream slots (slot_stride bytes each), bit counts and start planes per rank: rank r's rows land in
+ * rows [r*B, (r+1)*B) of d_all_* (sizes world*B) on every rank.  Device pointers; queued on the context's stream
+ * after the encoder kernels queued before it -- the host does not block (spiht_ctx_synchronize to wait). */
+int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *comm, const uint8_t *d_slots, const uint64_t *d_nbits,
+                         const uint8_t *d_max_n, int64_t B, uint64_t slot_stride, uint8_t *d_all_slots,
+                         uint64_t *d_all_nbits, uint8_t *d_all_max_n);
+/* Host-side job control over the same communicator (both block): every rank has arrived and its context's queue is
+ * empty; *value becomes the maximum over ranks. */
+int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *comm);
+int spiht_comm_allreduce_max_f64(spiht_ctx *ctx, spiht_comm *comm, double *value);
+
 /* Thin device-memory helpers so a host language without a HIP binding can drive the batched API. */
 int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr);
 int spiht_dev_free(spiht_ctx *ctx, void *d_ptr);
 int spiht_dev_upload(spiht_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);
 int spiht_dev_download(spiht_ctx *ctx, void *h_dst, const void *d_src, uint64_t bytes);
 int spiht_dev_memset(spiht_ctx *ctx, void *d_dst, int value, uint64_t bytes);
+int spiht_dev_copy(spiht_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes); /* device to device, asynchronous */
 
 #ifdef __cplusplus
 }

@@ -152,14 +152,22 @@ static inline int64_t ext_index(int64_t i, int64_t N, int mode) {
     }
 }
 
-/* 1-D analysis along a strided line */
+/* 1-D analysis along a strided line.  Order of the additions as in pywt's downsampling_convolution
+ * (convolution.template.c): taps in ascending order, except for the outputs that hang over the right end (2o+1 >= N)
+ * of an input at least as long as the filter: there the taps that read the signal extension come first, nearest first
+ * (filter index 2o+1-N down to 0), then the others ascending.  (Constant-edge mode adds the replicated-edge taps in
+ * ascending order too; inputs shorter than the filter go through another loop of pywt's, restated here as plain
+ * ascending order.)  The truncating quantiser sees the difference on piecewise-constant 8-bit pictures:
+ * tests/golden/blocky_pywt.npz holds pywt's arrays bit for bit. */
 static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, const double *hi, int F,
                      int mode, double *ca, double *cd, int64_t so) {
     int64_t L = (N + F - 1) / 2;
     for (int64_t o = 0; o < L; o++) {
         double a = 0.0, d = 0.0;
-        for (int j = 0; j < F; j++) {
-            int64_t idx = ext_index(2 * o + 1 - j, N, mode);
+        int64_t i = 2 * o + 1, jb = (i >= N && N >= F && mode != MODE_CONSTANT) ? i - N : -1;
+        for (int s = 0; s < F; s++) {
+            int j = s <= jb ? (int)(jb - s) : s;
+            int64_t idx = ext_index(i - j, N, mode);
             double v = idx < 0 ? 0.0 : x[idx * sx];
             a += lo[j] * v;
             d += hi[j] * v;

@@ -192,6 +192,18 @@ def start_plane(maxabs, rule=RULE_RUST):
     return int(lib().orc_start_plane(maxabs, rule))
 
 
+def set_codes(x, ll_h, ll_w):
+    """Significance of every node's D and L sets by the reference's recursion (encoder_decoder.rs:78-121, :228-237):
+    -> (dcode, lcode, has_offspring) uint8 [c,h,w]; a set is significant at plane n iff its code > n."""
+    x = np.ascontiguousarray(x, dtype=np.int32)
+    c, h, w = x.shape
+    d, l, has = (np.zeros((c, h, w), dtype=np.uint8) for _ in range(3))
+    L = lib()
+    L.orc_set_codes.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p] * 3
+    _check(L.orc_set_codes(x.ctypes.data, c, h, w, ll_h, ll_w, d.ctypes.data, l.ctypes.data, has.ctypes.data))
+    return d, l, has.astype(bool)
+
+
 def get_offspring(i, j, h, w, ll_h, ll_w):
     o = np.zeros((4, 2), dtype=np.int64)
     has = lib().orc_get_offspring(i, j, h, w, ll_h, ll_w, o.ctypes.data)

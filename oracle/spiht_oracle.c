@@ -689,3 +689,31 @@ int orc_decode(const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64
     free(bits);
     return rc;
 }
+
+/* Set significance of every node, evaluated with the reference's own recursion (test helper for the GPU's
+ * significance pyramid, which replaces it):
+ *   dcode[k,i,j] = 1 + the largest plane n at which the type-A test of encoder_decoder.rs:228-237 passes for
+ *                  node (k,i,j) -- any offspring o with is_set_sig(o, n), :78-99 -- or 0 if it passes at no plane;
+ *   lcode[k,i,j] = the same for the type-B test is_l_sig (:101-121);
+ *   has[k,i,j]   = 1 iff get_offspring (:43-75) returns Some for the node.
+ * "significant at plane n"  <=>  code > n.  Nodes without offspring get 0. */
+int orc_set_codes(const int32_t *x, int64_t c, int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, uint8_t *dcode,
+                  uint8_t *lcode, uint8_t *has) {
+    view3 a = {x, c, h, w, h * w, w, 1};
+    if (!(ll_h > 1) || !(ll_w > 1)) return ORC_ERR_LL;
+    for (int64_t k = 0; k < c; k++)
+        for (int64_t i = 0; i < h; i++)
+            for (int64_t j = 0; j < w; j++) {
+                const int64_t t = (k * h + i) * w + j;
+                int64_t o[4][2];
+                dcode[t] = 0; lcode[t] = 0;
+                has[t] = (uint8_t)orc_get_offspring(i, j, h, w, ll_h, ll_w, o);
+                if (!has[t]) continue;
+                for (int n = 30; n >= 0 && !dcode[t]; n--)
+                    for (int q = 0; q < 4; q++)
+                        if (is_set_sig(&a, k, o[q][0], o[q][1], (uint8_t)n, ll_h, ll_w)) { dcode[t] = (uint8_t)(n + 1); break; }
+                for (int n = 30; n >= 0 && !lcode[t]; n--)
+                    if (is_l_sig(&a, k, i, j, (uint8_t)n, ll_h, ll_w)) lcode[t] = (uint8_t)(n + 1);
+            }
+    return ORC_OK;
+}

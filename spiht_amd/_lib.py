@@ -41,7 +41,11 @@ SYMBOLS = [
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
     "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
     "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
-    "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset",
+    "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset", "spiht_dev_copy",
+    "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
+    "spiht_dequant_idwt_host_f64",
+    "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
+    "spiht_comm_barrier", "spiht_comm_allreduce_max_f64",
 ]
 
 
@@ -110,6 +114,20 @@ def lib():
         L.spiht_dev_upload.argtypes = [vp, vp, vp, u64]
         L.spiht_dev_download.argtypes = [vp, vp, vp, u64]
         L.spiht_dev_memset.argtypes = [vp, vp, i32, u64]
+        L.spiht_dev_copy.argtypes = [vp, vp, vp, u64]
+        L.spiht_encode_image_host_f64.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, vp, u64,
+                                                  C.POINTER(u64), C.POINTER(u8)]
+        L.spiht_encode_image_host_f32.argtypes = L.spiht_encode_image_host_f64.argtypes
+        L.spiht_decode_image_host_f64.argtypes = [vp, vp, u64, u8, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_dequant_idwt_host_f64.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_comm_unique_id.argtypes = [vp]
+        L.spiht_comm_create.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
+        L.spiht_comm_destroy.argtypes = [vp]
+        L.spiht_comm_destroy.restype = None
+        L.spiht_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.spiht_gather_streams.argtypes = [vp, vp, vp, vp, vp, i64, u64, vp, vp, vp]
+        L.spiht_comm_barrier.argtypes = [vp, vp]
+        L.spiht_comm_allreduce_max_f64.argtypes = [vp, vp, C.POINTER(C.c_double)]
         _lib = L
         return _lib
 

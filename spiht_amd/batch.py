@@ -213,8 +213,10 @@ class OverlappedCodec:
             float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
         self.H.record(self.ev_i[s])
 
-    def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None):
-        """queue the round trip of one batch (device pointers as in BatchCodec.encode_device / decode_device)"""
+    def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None, dec_src=None):
+        """queue the round trip of one batch (device pointers as in BatchCodec.encode_device / decode_device).
+        dec_src = (d_slots, d_nbits, d_max_n): what the decoder reads instead of the encoder's own outputs -- e.g. this
+        rank's rows of the buffers `between` gathered the streams into."""
         cd, B, g = self.codec, self.B, self.codec.geom
         s = self.i & 1
         Lc = self.Ls[s]
@@ -242,9 +244,10 @@ class OverlappedCodec:
             vp(d_max_n)))
         if between is not None:
             between(Lc)
-        _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(d_nbits), B, vp(d_nbytes)))
+        x_out, x_nbits, x_max_n = dec_src if dec_src is not None else (d_out, d_nbits, d_max_n)
+        _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(x_nbits), B, vp(d_nbytes)))
         _lib.check(cd.L.spiht_decode_lists_batch_i32(
-            Lc.handle, vp(d_out), cd.slot_stride, vp(d_nbytes), vp(d_max_n), B, cd.c, g["enc_h"], g["enc_w"],
+            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, g["enc_h"], g["enc_w"],
             g["ll_h"], g["ll_w"], vp(self.rec[s].ptr)))
         Lc.record(self.ev_d[s])
         self.used[s] = True

@@ -76,12 +76,14 @@ struct DevBuf {
 struct spiht_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: the host-array entry points call the batched ones
     int num_cu = 256;
     float log2_thresh[32];
     // grow-only scratch
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
+    DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
+    std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -363,7 +365,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
-                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt};
+                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -378,7 +380,7 @@ static int clear_err(spiht_ctx *ctx);
 // queued since the last synchronize recorded.
 extern "C" int spiht_ctx_synchronize(spiht_ctx *ctx) {
     if (!ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     int st = read_err(ctx);  // includes the stream synchronize
     if (st != SPIHT_OK) {
@@ -403,14 +405,14 @@ extern "C" int spiht_ctx_wait_on(spiht_ctx *ctx, spiht_ctx *other) {
 }
 extern "C" int spiht_ctx_set_timing(spiht_ctx *ctx, int enabled) {
     if (!ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     drain_timing(ctx);
     ctx->timing = enabled != 0;
     return SPIHT_OK;
 }
 extern "C" int spiht_ctx_reset_timing(spiht_ctx *ctx) {
     if (!ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     drain_timing(ctx);
     for (int s = 0; s < ST_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
     return SPIHT_OK;
@@ -419,7 +421,7 @@ extern "C" int spiht_ctx_num_stages(void) { return ST_COUNT; }
 extern "C" const char *spiht_ctx_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? STAGE_NAMES[s] : ""; }
 extern "C" int spiht_ctx_get_timing(spiht_ctx *ctx, int stage, double *ms, uint64_t *launches) {
     if (!ctx || stage < 0 || stage >= ST_COUNT) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     drain_timing(ctx);
     if (ms) *ms = ctx->ms[stage];
     if (launches) *launches = ctx->launches[stage];
@@ -612,7 +614,7 @@ extern "C" int spiht_encode_i32(spiht_ctx *ctx, const int32_t *x, int64_t c, int
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (!x) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     // gather the strided view into a contiguous staging buffer (lib.rs:27 takes any strides)
     std::vector<int32_t> stage;
@@ -674,7 +676,7 @@ extern "C" int spiht_decode_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nb
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (n > 30) return SPIHT_ERR_MAGNITUDE;
     if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
     CHK(ensure(ctx, ctx->data, slot));
@@ -733,7 +735,7 @@ extern "C" int spiht_decode_with_metadata_i32(spiht_ctx *ctx, const uint8_t *dat
     }
     for (size_t t = 4; t < sl.size(); t += 4)
         if (sl[t + 1] < sl[t] || sl[t + 3] < sl[t + 2]) return SPIHT_ERR_SHAPE;  // usize underflow in end - start (:606-608)
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
     const uint64_t rows = nbytes * 8 + 1;
@@ -801,7 +803,7 @@ extern "C" int spiht_encode_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64_
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const int chunk = batch_chunk(g);
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
@@ -819,7 +821,7 @@ extern "C" int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uin
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out));
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
@@ -833,7 +835,7 @@ extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
     if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     if (d_maxabs) {  // null: the caller has max|x| already (spiht_dwt_pyramid_batch_f64 without the pyramid)
         StageTimer t(ctx, ST_ABSMAX);
@@ -883,9 +885,17 @@ extern "C" int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int 
 static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, const double **d_mults) {
     *d_mults = nullptr;
     if (!channel_mults) return SPIHT_OK;
+    // the same scales as last time (every call of a codec object): nothing to upload, nothing to wait for
+    if (ctx->mults.p && ctx->mults_host.size() == (size_t)c && !memcmp(ctx->mults_host.data(), channel_mults, (size_t)c * 8)) {
+        *d_mults = (const double *)ctx->mults.p;
+        return SPIHT_OK;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // queued kernels still read the old scales
+    ctx->mults_host.clear();
     CHK(ensure(ctx, ctx->mults, (size_t)c * 8));
     HIPCHK(hipMemcpyAsync(ctx->mults.p, channel_mults, (size_t)c * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));  // caller's array may be a temporary
+    ctx->mults_host.assign(channel_mults, channel_mults + c);
     *d_mults = (const double *)ctx->mults.p;
     return SPIHT_OK;
 }
@@ -1013,7 +1023,7 @@ static int dwt_quant_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int64_
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
     CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
@@ -1044,7 +1054,7 @@ extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
     CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
@@ -1070,7 +1080,7 @@ static int encode_image_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int
     CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
@@ -1119,7 +1129,7 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
     CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
@@ -1136,9 +1146,9 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
         // Internal coefficient array: it is all zero on entry and is left all zero -- after the inverse transform the
         // cells the decoder wrote are cleared again through its own LSP lists (about 1 % of the array) instead of
         // zero-filling 26 MB per 1080p image before every decode.
-        const void *old_p = ctx->recz.p;
+        const size_t old_cap = ctx->recz.cap;  // (the allocator may hand back the same address for a larger buffer)
         CHK(ensure(ctx, ctx->recz, (size_t)nb * g.n * 4));
-        if (ctx->recz.p != old_p || !ctx->recz_clean) {
+        if (ctx->recz.cap != old_cap || !ctx->recz_clean) {
             StageTimer t(ctx, ST_MEMSET);
             HIPCHK(hipMemsetAsync(ctx->recz.p, 0, ctx->recz.cap, ctx->stream));
             ctx->recz_clean = true;
@@ -1160,6 +1170,133 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
 }
 
 // ------------------------------------------------------------------------------------------------
+// the drop-in calls on host arrays: encode_image / decode_image / decode_from_rec_arr of the reference's wrapper
+// (spiht_wrapper.py:142-216, 259-281) as one C call each.  Pixels, stream and coefficient array live in the
+// context's grow-only device buffers -- no allocation per call after the first of a given size.
+// ------------------------------------------------------------------------------------------------
+static int encode_image_host(spiht_ctx *ctx, const void *img, bool f32, int64_t c, int64_t H, int64_t W, int wavelet,
+                             int mode, int level, double q_scale, const double *channel_mults, uint64_t max_bits,
+                             uint8_t *out, uint64_t out_cap, uint64_t *out_nbits, uint8_t *max_n) {
+    if (!ctx || !img || !out_nbits || !max_n || (!out && out_cap)) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, 1, c, H, W));
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    Geom g;
+    CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    uint64_t bits = bound_bits(g, 0x3FFFFFFFu);
+    if (max_bits != 0) bits = std::min(bits, max_bits);
+    if (bits >= 0xFFFFFF00ull * 8ull) return SPIHT_ERR_TOO_LARGE;
+    const uint64_t slot = std::max<uint64_t>(4, ((bits + 7) / 8 + 3) & ~3ull);
+    const size_t img_bytes = (size_t)c * H * W * (f32 ? 4 : 8);
+    CHK(ensure(ctx, ctx->himg, img_bytes));
+    CHK(ensure(ctx, ctx->out, slot));
+    CHK(ensure(ctx, ctx->nbits, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemcpyAsync(ctx->himg.p, img, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CHK(encode_image_batch(ctx, ctx->himg.p, f32, 1, c, H, W, wavelet, mode, level, q_scale, channel_mults, max_bits,
+                           (uint8_t *)ctx->out.p, slot, (uint64_t *)ctx->nbits.p, (uint8_t *)ctx->maxn.p, nullptr));
+    uint64_t nbits = 0;
+    uint8_t mn = 0;
+    HIPCHK(hipMemcpyAsync(&nbits, ctx->nbits.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(&mn, ctx->maxn.p, 1, hipMemcpyDeviceToHost, ctx->stream));
+    CHK(read_err(ctx));  // synchronises
+    *out_nbits = nbits;
+    *max_n = mn;
+    const uint64_t nbytes = (nbits + 7) / 8;
+    if (nbytes > out_cap) return SPIHT_ERR_CAPACITY;
+    if (nbytes) {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(out, ctx->out.p, nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+extern "C" int spiht_encode_image_host_f64(spiht_ctx *ctx, const double *img, int64_t c, int64_t H, int64_t W, int wavelet,
+                                           int mode, int level, double q_scale, const double *channel_mults,
+                                           uint64_t max_bits, uint8_t *out, uint64_t out_cap, uint64_t *out_nbits,
+                                           uint8_t *max_n) {
+    return encode_image_host(ctx, img, false, c, H, W, wavelet, mode, level, q_scale, channel_mults, max_bits, out, out_cap,
+                             out_nbits, max_n);
+}
+extern "C" int spiht_encode_image_host_f32(spiht_ctx *ctx, const float *img, int64_t c, int64_t H, int64_t W, int wavelet,
+                                           int mode, int level, double q_scale, const double *channel_mults,
+                                           uint64_t max_bits, uint8_t *out, uint64_t out_cap, uint64_t *out_nbits,
+                                           uint8_t *max_n) {
+    return encode_image_host(ctx, img, true, c, H, W, wavelet, mode, level, q_scale, channel_mults, max_bits, out, out_cap,
+                             out_nbits, max_n);
+}
+
+extern "C" int spiht_decode_image_host_f64(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c,
+                                           int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                           const double *channel_mults, double *img_out) {
+    if (!ctx || !img_out || (!data && nbytes)) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, 1, c, H, W));
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    if (n > 30) return SPIHT_ERR_MAGNITUDE;
+    if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
+    const size_t out_bytes = (size_t)c * ig.rec_H * ig.rec_W * 8;
+    CHK(ensure(ctx, ctx->data, slot));
+    CHK(ensure(ctx, ctx->nbytes, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(ensure(ctx, ctx->himg, out_bytes));
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemsetAsync((char *)ctx->data.p + (slot - 4), 0, 4, ctx->stream));  // the bytes past the stream in its last word
+        if (nbytes) HIPCHK(hipMemcpyAsync(ctx->data.p, data, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->nbytes.p, &nbytes, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->maxn.p, &n, 1, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // &nbytes / &n are stack temporaries
+    }
+    CHK(spiht_decode_image_batch_f64(ctx, (const uint8_t *)ctx->data.p, slot, (const uint64_t *)ctx->nbytes.p,
+                                     (const uint8_t *)ctx->maxn.p, 1, c, H, W, wavelet, mode, level, q_scale, channel_mults,
+                                     (double *)ctx->himg.p, nullptr));
+    CHK(read_err(ctx));
+    {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(img_out, ctx->himg.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_dequant_idwt_host_f64(spiht_ctx *ctx, const int32_t *rec, int64_t c, int64_t H, int64_t W, int wavelet,
+                                           int mode, int level, double q_scale, const double *channel_mults,
+                                           double *img_out) {
+    if (!ctx || !rec || !img_out) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, 1, c, H, W));
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t rec_bytes = (size_t)c * ig.enc_h * ig.enc_w * 4, out_bytes = (size_t)c * ig.rec_H * ig.rec_W * 8;
+    CHK(ensure(ctx, ctx->hrec, rec_bytes));
+    CHK(ensure(ctx, ctx->himg, out_bytes));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemcpyAsync(ctx->hrec.p, rec, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    CHK(spiht_dequant_idwt_batch_f64(ctx, (const int32_t *)ctx->hrec.p, 1, c, H, W, wavelet, mode, level, q_scale,
+                                     channel_mults, (double *)ctx->himg.p));
+    {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(img_out, ctx->himg.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // the two halves of each direction on their own, so a caller can run the HBM-bound half of one batch on one
 // context while another context list-codes a different batch (bench.py)
 // ------------------------------------------------------------------------------------------------
@@ -1174,7 +1311,7 @@ extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, 
     CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
@@ -1201,7 +1338,7 @@ extern "C" int spiht_encode_lists_batch_i32(spiht_ctx *ctx, const int32_t *d_x, 
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;
     ListCaps caps;
@@ -1230,7 +1367,7 @@ extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_dat
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     DecArgs da;
     CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false, &da));
@@ -1247,7 +1384,7 @@ extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_dat
 extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w) {
     if (!ctx || !d_out || B < 0 || c < 1 || h < 1 || w < 1) return SPIHT_ERR_ARG;
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     StageTimer t(ctx, ST_MEMSET);
     const DecArgs &da = ctx->last_dec;
@@ -1265,7 +1402,7 @@ extern "C" int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double
                                       const double *A, const double *M, double p) {
     if (!ctx || !d_in || !d_out || !A || !M || B < 0 || npix < 1 || B > 65535) return SPIHT_ERR_ARG;
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     LAUNCHCHK(spiht_launch_color3(d_in, d_out, (int)B, (size_t)npix, A, M, p, ctx->stream));
     return SPIHT_OK;
@@ -1310,7 +1447,7 @@ extern "C" void spiht_event_destroy(spiht_event *e) {
 // marks the point reached by the work queued on ctx so far
 extern "C" int spiht_event_record(spiht_event *e, spiht_ctx *ctx) {
     if (!e || !ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipEventRecord(e->ev, ctx->stream));
     return SPIHT_OK;
@@ -1318,7 +1455,7 @@ extern "C" int spiht_event_record(spiht_event *e, spiht_ctx *ctx) {
 // work queued on ctx after this call starts only when the recorded point has been reached
 extern "C" int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *e) {
     if (!e || !ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamWaitEvent(ctx->stream, e->ev, 0));
     return SPIHT_OK;
@@ -1327,7 +1464,7 @@ extern "C" int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *e) {
 extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes) {
     if (!ctx || !d_nbits || !d_nbytes || B < 0) return SPIHT_ERR_ARG;
     if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     LAUNCHCHK(spiht_launch_nbits_to_nbytes(d_nbits, (int)B, d_nbytes, ctx->stream));
     return SPIHT_OK;
@@ -1338,7 +1475,7 @@ extern "C" int spiht_launch_spin(int blocks, int threads, uint64_t ticks, uint32
 // diagnostic, not part of the ABI header: occupy the GPU with `blocks` idle workgroups for `ticks` clock ticks
 extern "C" int spiht_debug_spin(spiht_ctx *ctx, int blocks, int threads, uint64_t ticks, uint32_t lds_bytes) {
     if (!ctx) return SPIHT_ERR_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     LAUNCHCHK(spiht_launch_spin(blocks, threads, ticks, lds_bytes, (uint32_t *)ctx->err.p + 8, ctx->stream));
     return SPIHT_OK;
@@ -1350,6 +1487,179 @@ extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out64, ctx->err.p, 256, hipMemcpyDeviceToHost));
     return SPIHT_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU: the one exchange of the path -- an all-gather of the stream slots, bit counts and start planes between
+// encode and decode -- on RCCL, queued on the context's stream like every kernel.  librccl is loaded
+// on first use (a single-GPU process never touches it); no link-time dependency.
+// ------------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static int rccl_load() {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.h) return SPIHT_OK;
+    const char *names[] = {getenv("SPIHT_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) {
+        const char *e = dlerror();
+        g_hip_err = std::string("cannot load librccl: ") + (e ? e : "?");
+        return SPIHT_ERR_HIP;
+    }
+    RcclApi a;
+    a.h = h;
+#define RSYM(field, name)                                                                \
+    do {                                                                                  \
+        *(void **)(&a.field) = dlsym(h, name);                                            \
+        if (!a.field) { g_hip_err = std::string("librccl lacks ") + name; dlclose(h); return SPIHT_ERR_HIP; } \
+    } while (0)
+    RSYM(GetUniqueId, "ncclGetUniqueId");
+    RSYM(CommInitRank, "ncclCommInitRank");
+    RSYM(CommDestroy, "ncclCommDestroy");
+    RSYM(AllGather, "ncclAllGather");
+    RSYM(AllReduce, "ncclAllReduce");
+    RSYM(GroupStart, "ncclGroupStart");
+    RSYM(GroupEnd, "ncclGroupEnd");
+    RSYM(GetErrorString, "ncclGetErrorString");
+    RSYM(GetVersion, "ncclGetVersion");
+#undef RSYM
+    g_rccl = a;
+    return SPIHT_OK;
+}
+
+#define NCCLCHK(expr)                                                                      \
+    do {                                                                                   \
+        ncclResult_t _r = (expr);                                                          \
+        if (_r != ncclSuccess) {                                                           \
+            g_hip_err = std::string(#expr) + ": " + g_rccl.GetErrorString(_r);             \
+            return SPIHT_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+struct spiht_comm {
+    ncclComm_t comm = nullptr;
+    int world = 1, rank = 0, device = 0;
+    void *scratch = nullptr;  // 16 device bytes for the barrier / the scalar reductions
+};
+
+static_assert(SPIHT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+
+extern "C" int spiht_comm_unique_id(uint8_t *id) {
+    if (!id) return SPIHT_ERR_ARG;
+    CHK(rccl_load());
+    ncclUniqueId u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.internal, SPIHT_COMM_ID_BYTES);
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_comm_create(spiht_ctx *ctx, const uint8_t *id, int world, int rank, spiht_comm **out) {
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return SPIHT_ERR_ARG;
+    *out = nullptr;
+    CHK(rccl_load());
+    HIPCHK(hipSetDevice(ctx->device));
+    ncclUniqueId u;
+    memcpy(u.internal, id, SPIHT_COMM_ID_BYTES);
+    spiht_comm *c = new spiht_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = ctx->device;
+    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        g_hip_err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+        delete c;
+        return SPIHT_ERR_HIP;
+    }
+    if (hipMalloc(&c->scratch, 16) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)g_rccl.CommDestroy(c->comm);
+        delete c;
+        return SPIHT_ERR_NOMEM;
+    }
+    *out = c;
+    return SPIHT_OK;
+}
+
+extern "C" void spiht_comm_destroy(spiht_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    delete c;
+}
+
+extern "C" int spiht_comm_info(spiht_comm *c, int *world, int *rank, int *rccl_version) {
+    if (!c) return SPIHT_ERR_ARG;
+    if (world) *world = c->world;
+    if (rank) *rank = c->rank;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (g_rccl.GetVersion) (void)g_rccl.GetVersion(rccl_version);
+    }
+    return SPIHT_OK;
+}
+
+// Rank r's B slots / bit counts / start planes land in rows [r*B, (r+1)*B) of the gathered arrays on every rank
+// (spiht_amd/dist.py: rank-major).  Three all-gathers in one RCCL group, queued on the context's stream: ordered
+// after the encoder kernels queued before and before the decoder kernels queued after; the host does not block.
+extern "C" int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *c, const uint8_t *d_slots, const uint64_t *d_nbits,
+                                    const uint8_t *d_max_n, int64_t B, uint64_t slot_stride, uint8_t *d_all_slots,
+                                    uint64_t *d_all_nbits, uint8_t *d_all_max_n) {
+    if (!ctx || !c || !d_slots || !d_nbits || !d_max_n || !d_all_slots || !d_all_nbits || !d_all_max_n || B < 0)
+        return SPIHT_ERR_ARG;
+    if (c->device != ctx->device) return SPIHT_ERR_ARG;
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    NCCLCHK(g_rccl.GroupStart());
+    ncclResult_t r1 = g_rccl.AllGather(d_slots, d_all_slots, (size_t)B * slot_stride, ncclUint8, c->comm, ctx->stream);
+    ncclResult_t r2 = g_rccl.AllGather(d_nbits, d_all_nbits, (size_t)B, ncclUint64, c->comm, ctx->stream);
+    ncclResult_t r3 = g_rccl.AllGather(d_max_n, d_all_max_n, (size_t)B, ncclUint8, c->comm, ctx->stream);
+    NCCLCHK(g_rccl.GroupEnd());
+    NCCLCHK(r1);
+    NCCLCHK(r2);
+    NCCLCHK(r3);
+    return SPIHT_OK;
+}
+
+// max over ranks of a host double (timing: the job's time is its slowest rank's); blocks until done
+extern "C" int spiht_comm_allreduce_max_f64(spiht_ctx *ctx, spiht_comm *c, double *value) {
+    if (!ctx || !c || !value || c->device != ctx->device) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(c->scratch, value, 8, hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(g_rccl.AllReduce(c->scratch, c->scratch, 1, ncclFloat64, ncclMax, c->comm, ctx->stream));
+    HIPCHK(hipMemcpyAsync(value, c->scratch, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+// every rank has reached this call and everything queued on its context's stream before it has finished
+extern "C" int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *c) {
+    double one = 1.0;
+    return spiht_comm_allreduce_max_f64(ctx, c, &one);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1385,6 +1695,12 @@ extern "C" int spiht_dev_download(spiht_ctx *ctx, void *h_dst, const void *d_src
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+extern "C" int spiht_dev_copy(spiht_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes) {
+    if (!ctx || (!d_dst && bytes) || (!d_src && bytes)) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return SPIHT_OK;
 }
 extern "C" int spiht_dev_memset(spiht_ctx *ctx, void *d_dst, int value, uint64_t bytes) {

@@ -16,10 +16,12 @@
 //     they rebuild entry starts from the mask, lane = stream position, and produce next generation / retained list /
 //     LIP / LSP appends; the running list lengths pass from worker to worker through a small LDS chain.
 //   * refinement: bit t belongs to LSP entry t -- all wavefronts, no sequencing.
-// Decoded magnitudes live next to the LSP (lsp_val) and are scattered into the coefficient array at the end;
-// the few operations that consumed one of the last 8 bits of the stream (possible pad bits, Q9) are replayed
-// serially in stream order so duplicated tree nodes (Q4) end exactly as the reference's sequential writes
-// leave them.
+// Decoded values live next to the LSP (lsp_val, one private value per list entry) and are scattered into the
+// coefficient array at the end.  On trees with duplicated nodes (odd ll_h / ll_w) two or three list
+// entries own the same cell; the reference's writes to it are sequential (encoder_decoder.rs:364-372, 396-404, 443),
+// so for such a cell the entries are brought together at the end (resolve_dups) and their operations -- all of them
+// recoverable from the private values -- are replayed in stream order: exact for any byte string, not only for
+// encoder-produced streams.
 #include "common.h"
 
 #ifndef DEC_NW
@@ -41,7 +43,6 @@ static_assert((DEC_RING & (DEC_RING - 1)) == 0 && DEC_RING <= DEC_NW * 64, "ring
 #ifndef DEC_WSLEEP
 #define DEC_WSLEEP 1  // s_sleep argument (x64 cycles) of a worker waiting for its next window
 #endif
-#define DEC_TAIL 16
 #define SEQ_OPEN 0xFFFFFFFFu
 #define SPIN_LIMIT (1u << 24)  // bound on every LDS spin (about a second): a protocol bug must not hang the GPU
 
@@ -52,13 +53,6 @@ static_assert((DEC_RING & (DEC_RING - 1)) == 0 && DEC_RING <= DEC_NW * 64, "ring
 #define PF_ADD(k)
 #define PF_CNT(k, v)
 #endif
-
-struct TailOp {
-    uint32_t key;  // stream position of the deciding bit (replay order)
-    uint32_t idx;
-    int32_t val;   // value for a write, bit for a refine
-    uint32_t n;    // plane; bit 31 set: refine, clear: write
-};
 
 struct Item {  // one 64-bit stream window of one pass
     uint32_t kind;        // 0 = LIP window, 1 = LIS window
@@ -127,11 +121,9 @@ struct DecShared {
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
     uint32_t wdone[DEC_NWK];    // items completed per worker
-    uint32_t ntail;
     uint32_t bad;
     // results of a phase, written by the sequencer before the closing barrier
     uint32_t r_P, r_done, r_lsp, r_lip;
-    TailOp tail[DEC_TAIL];
 };
 
 __device__ __forceinline__ uint32_t lds_load(uint32_t *p) {
@@ -371,11 +363,6 @@ __device__ __forceinline__ Item slot_unpack(DecShared &sh, const BitSrc &bs, uin
     return it;
 }
 
-__device__ __forceinline__ void tail_push(DecShared &sh, uint32_t key, uint32_t idx, int32_t val, uint32_t n) {
-    const uint32_t tp = atomicAdd(&sh.ntail, 1u);
-    if (tp < DEC_TAIL) { sh.tail[tp].key = key; sh.tail[tp].idx = idx; sh.tail[tp].val = val; sh.tail[tp].n = n; }
-}
-
 // ---- decode_with_metadata trace (k_decode<true> only): which list entry every stream position belongs to ----
 struct Trace {
     uint32_t *ent;
@@ -391,11 +378,120 @@ __device__ __forceinline__ void tr_put(const Trace &tr, uint32_t pos, uint32_t a
     }
 }
 
+// ---- duplicated cells ----
+// get_offspring (encoder_decoder.rs:43-75) maps root (i,j) to the 2x2 block at rows (i&1)*ll_h + (i&~1) .. +1, columns
+// likewise.  With an odd ll_h the blocks of the even roots reach row ll_h, where the blocks of the odd roots start:
+// a first-generation node in row ll_h (and, the same way, in column ll_w when ll_w is odd) whose other coordinate
+// lies in the odd roots' range is the offspring of two roots (of three at the corner), and so is every node of its
+// sub-tree.  Each instance travels through the lists on its own.
+__device__ __forceinline__ bool dup_cell(const Geom &g, uint32_t idx) {
+    uint32_t k, i, j;
+    decomp(g, idx, k, i, j);
+    const uint32_t lh = (uint32_t)g.ll_h, lw = (uint32_t)g.ll_w;
+    // cheap rejection: a node of such a sub-tree has the bits of ll_h (ll_w) at the top of its row (column) index
+    const int si = (int)__clz((int)lh) - (int)__clz((int)i), sj = (int)__clz((int)lw) - (int)__clz((int)j);
+    const bool ri = (lh & 1u) && i >= lh && (i >> si) == lh, rj = (lw & 1u) && j >= lw && (j >> sj) == lw;
+    if (!ri && !rj) return false;
+    // first-generation ancestor: halve while the index-doubling parent is outside the root block
+    while (!((i >> 1) < lh && (j >> 1) < lw)) { i >>= 1; j >>= 1; }
+    const bool io = i >= lh && (((i - lh) & ~1u) + 1u) < lh;  // row of an odd root's block
+    const bool jo = j >= lw && (((j - lw) & ~1u) + 1u) < lw;
+    return ((lh & 1u) && i == lh && jo) || ((lw & 1u) && j == lw && io);
+}
+
+// Final value of a cell owned by `cnt` LSP entries (ascending LSP index = stream order of their first writes), from
+// the entries' private values: entry X was written at plane nX = msb|vX| with the sign of vX, and bit m < nX of |vX|
+// is the refinement bit X read at plane m.  The reference applies all of it to ONE cell (encoder_decoder.rs:364-372,
+// 396-404: rec = +-1.5*2^n; :443: rec = set_bit(rec, n, bit)), plane by plane: the writes of the LIP and LIS passes
+// (LSP order), then the refinement pass over the entries appended in earlier planes (LSP order).
+__device__ __forceinline__ int32_t replay_dup(const uint32_t (&ts)[3], const int32_t (&vs)[3], int cnt, uint32_t ref_plane,
+                                              uint32_t ref_count) {
+    int nx[3] = {-1, -1, -1};
+    uint32_t mag[3] = {0, 0, 0};
+    int top = 0;
+    for (int q = 0; q < cnt; q++) {
+        mag[q] = (uint32_t)(vs[q] < 0 ? -vs[q] : vs[q]);
+        nx[q] = 31 - (int)__clz((int)mag[q]);
+        top = nx[q] > top ? nx[q] : top;
+    }
+    int32_t cur = 0;
+    for (int m = top; m >= 0; --m) {
+        for (int q = 0; q < cnt; q++)
+            if (nx[q] == m) {
+                const int32_t base = m == 0 ? 1 : (int32_t)(3u << (m - 1));
+                cur = vs[q] < 0 ? -base : base;
+            }
+        if ((uint32_t)m >= ref_plane)
+            for (int q = 0; q < cnt; q++)
+                if (nx[q] > m && ((uint32_t)m > ref_plane || ts[q] < ref_count)) cur = set_bit_i32(cur, (uint32_t)m, (mag[q] >> m) & 1u);
+    }
+    return cur;
+}
+
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypasses the L1: the word is the target of L2 atomics
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Brings the LSP entries of every duplicated cell together and writes the cell.  No hash table: the entries meet in
+// the (still zero) cell itself -- atomicMax of LSP index + 1 elects the newest entry as owner -- and the others post
+// their index into the owner's two mail words (mailA / mailB: the LIP buffers, free by now; indexed by LSP index).
+// All waves of the workgroup; barriers between the rounds.
+template <uint32_t IDXM>
+__device__ __forceinline__ void resolve_dups(const Geom &g, int32_t *out, const uint32_t *lsp_idx, const int32_t *lsp_val,
+                                             uint32_t lsp_len, uint32_t *mailA, uint32_t *mailB, uint32_t ref_plane,
+                                             uint32_t ref_count) {
+    constexpr uint32_t NT = DEC_NW * 64, OWNER = 0xFFFFFFFFu;
+    uint32_t *cells = reinterpret_cast<uint32_t *>(out);
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 0: elect
+        const uint32_t idx = lsp_idx[t] & IDXM;
+        if (!dup_cell(g, idx)) continue;
+        mailA[t] = 0;
+        mailB[t] = 0;
+        atomicMax(&cells[idx], t + 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 1: the newest of the others
+        const uint32_t idx = lsp_idx[t] & IDXM;
+        if (!dup_cell(g, idx)) continue;
+        const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
+        if (t1 != t) atomicMax(&mailA[t1], t + 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 2: a third entry (corner cells)
+        const uint32_t idx = lsp_idx[t] & IDXM;
+        if (!dup_cell(g, idx)) continue;
+        const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
+        if (t1 != t && ld_l2(&mailA[t1]) != t + 1u) atomicMax(&mailB[t1], t + 1u);
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 3: the owner replays
+        const uint32_t idx = lsp_idx[t] & IDXM;
+        if (!dup_cell(g, idx)) continue;
+        if (ld_l2(&cells[idx]) - 1u != t) continue;
+        const uint32_t m2 = ld_l2(&mailA[t]), m3 = ld_l2(&mailB[t]);
+        uint32_t ts[3] = {0, 0, 0};
+        int32_t vs[3] = {0, 0, 0};
+        int cnt = 0;
+        if (m3) { ts[cnt] = m3 - 1u; vs[cnt] = lsp_val[m3 - 1u]; cnt++; }
+        if (m2) { ts[cnt] = m2 - 1u; vs[cnt] = lsp_val[m2 - 1u]; cnt++; }
+        ts[cnt] = t; vs[cnt] = lsp_val[t]; cnt++;
+        mailA[t] = (uint32_t)replay_dup(ts, vs, cnt, ref_plane, ref_count);
+        mailB[t] = OWNER;
+    }
+    __syncthreads();  // every entry has read the election result: the cells can take their values
+    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 4 (an owner reads back its own two stores)
+        const uint32_t idx = lsp_idx[t] & IDXM;
+        if (!dup_cell(g, idx)) continue;
+        if (mailB[t] == OWNER) out[idx] = (int32_t)mailA[t];
+    }
+}
+
 // ---- per-lane work of one LIP window (worker) ----
 template <bool META>
 __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const Item &it, const uint32_t *lip,
                                          uint32_t *lipn, uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits,
-                                         uint32_t tail_start, int n, int32_t base_val, uint32_t lane, const Trace &tr) {
+                                         int n, int32_t base_val, uint32_t lane, const Trace &tr) {
     const LipWin lw = lip_window(it.lo, it.Wb, it.pos0, it.cin, it.m_rem, nbits);
     const bool isS = (lw.S_in >> lane) & 1ull;
     const uint32_t rank = mbcnt(lw.S_in);
@@ -416,12 +512,10 @@ __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const 
         const uint32_t sgn = lane < 63 ? ((uint32_t)(it.lo >> (lane + 1)) & 1u) : ((uint32_t)it.hi & 1u);
         const uint32_t t = it.b_lsp + mbcnt(lw.sig);
         const int32_t v = sgn ? base_val : -base_val;
-        const bool tl = it.Wb + lane + 1 >= tail_start;
         if (t < a.caps.lsp) {
             lsp_idx[t] = e;
-            lsp_val[t] = tl ? 0 : v;
+            lsp_val[t] = v;
         }
-        if (tl) tail_push(sh, it.Wb + lane + 1, e, v, (uint32_t)n);
     } else if (isS) {
         lipn[it.b_lip + mbcnt(lw.S_in & ~lw.sig)] = e;
     }
@@ -431,7 +525,7 @@ __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const 
 template <bool META>
 __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const Geom &g, const Item &it, uint32_t seqno,
                                          const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
-                                         uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
+                                         uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
                                          int32_t base_val, uint32_t lane, const Trace &tr) {
     const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
     constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
@@ -459,7 +553,7 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
     const bool isA = (e & ENT_A) != 0;
     const bool leaf = (e & ENT_LEAF) != 0;
     uint32_t nQ = 0, nR = 0, nLIP = 0, nLSP = 0;
-    uint32_t sigm = 0, signm = 0, lipm = 0, tailm = 0, cb = 0, cr = 0, ccol = 0;
+    uint32_t sigm = 0, signm = 0, lipm = 0, cb = 0, cr = 0, ccol = 0;
     uint32_t cf = 0;  // META: filter of the offspring, in entry position (get_offspring_filter, :133-150)
     bool fired = false;
     if (META && isE) tr_put(tr, mypos, isA ? 2u : 5u, n, e);  // action 2 (:735) / action 5 (:787)
@@ -502,7 +596,6 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
                             else {
                                 sigm |= 1u << q;
                                 signm |= ((bits >> (o + 1)) & 1u) << q;
-                                if (mypos + o + 1 >= tail_start) tailm |= 1u << q;
                                 o += 2;
                             }
                         } else {
@@ -563,21 +656,15 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
         } else {
             uint32_t ol = b_lip + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
             uint32_t os = b_lsp + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
-            uint32_t o = 1;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t ci = (cb + (q >> 1) * W + (q & 1)) | cf;
                 if (sigm & (1u << q)) {
-                    const int32_t v = ((signm >> q) & 1u) ? base_val : -base_val;
-                    const bool tl = (tailm >> q) & 1u;
                     lsp_idx[os] = ci;
-                    lsp_val[os] = tl ? 0 : v;
+                    lsp_val[os] = ((signm >> q) & 1u) ? base_val : -base_val;
                     os++;
-                    if (tl) tail_push(sh, mypos + o + 1, ci, v, (uint32_t)n);
-                    o += 2;
                 } else if (lipm & (1u << q)) {
                     lip[ol++] = ci;
-                    o += 1;
                 }
             }
             if (nQ) nxt[b_nxt + mbcnt(mQ1) + 4u * mbcnt(mQ4)] = e & ~(ENT_A | ENT_LEAF);  // type B
@@ -590,7 +677,7 @@ template <bool META>
 __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, const Geom &g, uint32_t &myk, uint32_t par,
                                              const uint32_t *lip_rd, uint32_t *lip_wr, uint32_t *lip_app,
                                              const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lsp_idx,
-                                             int32_t *lsp_val, uint32_t nbits, uint32_t tail_start, int n,
+                                             int32_t *lsp_val, uint32_t nbits, int n,
                                              int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr,
                                              const BitSrc &bs) {
     for (;;) {
@@ -611,7 +698,7 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
         }
         if (!got) break;
         const Item it = slot_unpack(sh, bs, myk);
-        work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
+        work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
         myk += DEC_NWK;
@@ -702,7 +789,6 @@ void k_decode(DecArgs a) {
         if (nby > a.slot_stride) { bad = true; nby = 0; }
         bs.nbits = (uint32_t)(nby * 8);
         const uint32_t nbits = bs.nbits;
-        const uint32_t tail_start = nbits >= 8 ? nbits - 8 : 0;
         Trace tr;
         tr.ent = META ? a.tr_ent + (size_t)b * a.tr_stride : nullptr;
         tr.act = META ? a.tr_act + (size_t)b * a.tr_stride : nullptr;
@@ -714,7 +800,10 @@ void k_decode(DecArgs a) {
         uint32_t *lip = lipA, *lipn = lipB;
         uint32_t *lis = q0, *qa = q1, *qb = q2;
         uint32_t lip_len = 0, lsp_len = 0, lis_len = 0;
-        uint32_t P = 0, cut = 0;
+        uint32_t P = 0;
+        // refinement passes that ran: every plane above ref_plane completely, plane ref_plane for the first ref_count
+        // LSP entries, no plane below (resolve_dups replays duplicated cells from this)
+        uint32_t ref_plane = 32, ref_count = 0;
         uint32_t seq = 0;                    // items produced so far (kept in step by every wave at phase ends)
         uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
@@ -725,7 +814,7 @@ void k_decode(DecArgs a) {
 
         __syncthreads();  // previous image fully finished with the shared state
         if (threadIdx.x == 0) {
-            sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.ntail = 0; sh.bad = 0;
+            sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.bad = 0;
             sh.pprog = 0; sh.sprog = 0;
             for (int w = 0; w < DEC_NWK; w++) sh.wdone[w] = 0;
             for (int r = 0; r < DEC_RING; r++) { sh.chain[r].seq = 0; sh.ring[r].ready = 0; }
@@ -860,7 +949,7 @@ void k_decode(DecArgs a) {
                             it.kind = 0; it.Wb = q.Wb; it.pos0 = q.flags & 0xFFu; it.pos1 = 64; it.e_start = q.e_start;
                             it.cin = (q.flags >> 8) & 1u; it.m_rem = q.m_rem; it.first = 1; it.b_lsp = q.b_lsp; it.b_lip = q.b_lip;
                             it.b_nxt = 0; it.b_ret = 0; it.lo = q.lo; it.hi = (q.flags >> 9) & 1u; it.fm = 0;
-                            work_lip<META>(sh, a, it, lip, lipn, lsp_idx, lsp_val, nbits, tail_start, n, base_val, lane, tr);
+                            work_lip<META>(sh, a, it, lip, lipn, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
                         }
                     }
                     // ---- advance (every wave computes the same) ----
@@ -1078,7 +1167,7 @@ void k_decode(DecArgs a) {
                     helper_phase(sh, bs, par, P >> 6, lane);
                 } else if (DEC_IS_WORKER(wave)) {
                     worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,
-                                       tail_start, n, base_val, DEC_WK(wave), lane, tr, bs);
+                                       n, base_val, DEC_WK(wave), lane, tr, bs);
                 }
                 PF_ADD(2);
                 __syncthreads();
@@ -1122,15 +1211,15 @@ void k_decode(DecArgs a) {
                     for (int u = 0; u < 4; u++) {
                         const uint32_t t = t0 + (uint32_t)u * 64 + lane;
                         const bool in = t < count;
-                        const bool tl = in && (P + t >= tail_start);
-                        if (in && !tl) lsp_val[t] = set_bit_i32(v[u], (uint32_t)n, bit[u]);
-                        if (tl) tail_push(sh, P + t, lsp_idx[t], (int32_t)bit[u], (uint32_t)n | 0x80000000u);
+                        if (in) lsp_val[t] = set_bit_i32(v[u], (uint32_t)n, bit[u]);
                         if (META && in) tr_put(tr, P + t, 6, n, lsp_idx[t]);  // action 6 (:822)
                     }
                 }
                 if (META && count < lsp_len0 && threadIdx.x == 0) tr_put(tr, nbits, 6, n, lsp_idx[count]);  // waiting
                 P += count;
-                if (count < lsp_len0) { cut = count; done = true; }
+                ref_plane = (uint32_t)n;
+                ref_count = count;
+                if (count < lsp_len0) done = true;
                 __syncthreads();
                 PF_ADD(4);
             }
@@ -1140,13 +1229,17 @@ void k_decode(DecArgs a) {
         // ---------------- scatter decoded values ----------------
         __syncthreads();
         PF_ADD(7);
+        // With an odd ll_h or ll_w some cells are owned by two or three list entries (dup_cell); those are left out here
+        // and resolved below.
+        const bool dups = ((g.ll_h | g.ll_w) & 1) != 0;
         // Four entries per thread per batch, and the loads of the next batch are issued BEFORE the stores of this one:
         // loads and stores retire through one in-order counter (vmcnt), so a load issued after a scattered store
         // cannot be waited for without waiting for that store to be acknowledged (a plain loop pays load latency +
         // store latency per batch; the stores may alias the lists as far as the compiler knows, so it keeps this order).
         // Two register sets, alternating, so that no register move has to wait for the newest loads.
-        auto scatter = [&](uint32_t t_begin, uint32_t t_end) {
+        {
             constexpr uint32_t STR = DEC_NW * 64, U = 4;
+            const uint32_t t_end = lsp_len;
             int32_t va[U], vb[U];
             uint32_t ia[U], ib[U];
             auto ld = [&](uint32_t t0, int32_t(&v)[U], uint32_t(&ix)[U]) {
@@ -1155,47 +1248,33 @@ void k_decode(DecArgs a) {
                     const uint32_t t = t0 + u * STR, tc = t < t_end ? t : t_end - 1u;
                     const int32_t lv = lsp_val[tc];
                     ix[u] = lsp_idx[tc];
-                    v[u] = t < t_end ? lv : 0;
+                    v[u] = t < t_end ? lv : 0;  // a decoded value is never 0
                 }
             };
             auto st = [&](const int32_t(&v)[U], const uint32_t(&ix)[U]) {
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++)
-                    if (v[u]) out[ix[u] & IDXM] = v[u];
+                    if (v[u] && !(dups && dup_cell(g, ix[u] & IDXM))) out[ix[u] & IDXM] = v[u];
             };
-            if (t_begin >= t_end) return;
-            uint32_t t0 = t_begin + threadIdx.x;
-            ld(t0, va, ia);
-            for (; t0 < t_end; t0 += 2 * STR * U) {
-                ld(t0 + STR * U, vb, ib);
-                st(va, ia);
-                ld(t0 + 2 * STR * U, va, ia);
-                st(vb, ib);
+            if (t_end > 0) {
+                uint32_t t0 = threadIdx.x;
+                ld(t0, va, ia);
+                for (; t0 < t_end; t0 += 2 * STR * U) {
+                    ld(t0 + STR * U, vb, ib);
+                    st(va, ia);
+                    ld(t0 + 2 * STR * U, va, ia);
+                    st(vb, ib);
+                }
             }
-        };
-        scatter(cut, lsp_len);
-        __syncthreads();
-        scatter(0, cut);
+        }
+        if (dups) resolve_dups<IDXM>(g, out, lsp_idx, lsp_val, lsp_len, lipA, lipB, ref_plane, ref_count);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t nt = sh.ntail < DEC_TAIL ? sh.ntail : DEC_TAIL;
-            // replay in stream order (keys are distinct bit positions)
-            for (uint32_t q = 0; q < nt; q++) {
-                uint32_t best = 0xFFFFFFFFu, bi = 0;
-                for (uint32_t r = 0; r < nt; r++)
-                    if (sh.tail[r].key < best) { best = sh.tail[r].key; bi = r; }
-                TailOp op = sh.tail[bi];
-                op.idx &= IDXM;
-                sh.tail[bi].key = 0xFFFFFFFFu;
-                if (op.n & 0x80000000u) out[op.idx] = set_bit_i32(out[op.idx], op.n & 0xFFu, (uint32_t)op.val);
-                else out[op.idx] = op.val;
-            }
             if (a.lsp_count) a.lsp_count[slot] = lsp_len;
             uint32_t ecode = 0;
             if (bad) ecode |= 1u | 0x100u;
             if (sh.bad == 1) ecode |= 1u | 0x200u;            // list capacity
             if (sh.bad == 2) ecode |= 1u | 0x400u;            // spin limit
-            if (sh.ntail > DEC_TAIL) ecode |= 1u | 0x800u;
             if (ecode) atomicOr(a.err, ecode);
 #ifdef DEC_PROF
             PF_ADD(9);

@@ -151,21 +151,84 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }
         const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        // outputs on the bottom / right overhang are summed again in PyWavelets' order by k_dwt_edge, which overwrites
+        // them and accounts for their magnitude
+        const bool mine = oh < a.ov_h && ow < a.ov_w;
         if (a.last) {
             const int32_t qaa = quant(aa, mk, a.q, has_m);
             co[(size_t)oh * a.enc_w + ow] = qaa;
-            amax = max(amax, iabs_u(qaa));
+            if (mine) amax = max(amax, iabs_u(qaa));
         } else {
             llo[(size_t)oh * a.out_w + ow] = aa;
         }
         co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;                 // 'ad' top-right
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;               // 'da' bottom-left
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
-        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+        if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
         if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+
+// ---- the bottom / right overhang of a float64 level, in PyWavelets' summation order -----------------------------
+// pywt's downsampling_convolution adds the taps in ascending order -- except for the outputs that hang over the end
+// of the input (2o+1 >= N, the last F/2 or so output rows and columns of a level): there the taps that read the signal
+// extension come first, nearest first (filter index 2o+1-N down to 0), then the others ascending.  The sums differ in
+// the last bits, and on 8-bit pictures with flat areas (coefficient x q exactly an integer) the truncating quantiser
+// turns that into +-1 (tests/golden/blocky_pywt.npz).  k_dwt_level keeps its compile-time ascending order everywhere;
+// this kernel then recomputes just those outputs, one thread each, straight from global memory (F*F loads per output,
+// a few thousand outputs per plane), and overwrites them.  grid: (ceil(outputs / 256), planes).
+__global__ __launch_bounds__(256) void k_dwt_edge(DwtKArgs a) {
+    const int F = a.F;
+    const int nr = a.out_h - a.ov_h, nc = a.out_w - a.ov_w;        // overhang rows / columns
+    const int nA = nr * a.out_w, total = nA + a.ov_h * nc;          // all columns of the overhang rows + the rest of the columns
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int plane = blockIdx.y;
+    uint32_t amax = 0;
+    if (t < total) {
+        int oh, ow;
+        if (t < nA) { oh = a.ov_h + t / a.out_w; ow = t % a.out_w; }
+        else { const int u = t - nA; oh = u / nc; ow = a.ov_w + u % nc; }
+        const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
+        const int ir = 2 * oh + 1, ic = 2 * ow + 1;
+        const int jbr = oh >= a.ov_h ? ir - a.in_h : -1, jbc = ow >= a.ov_w ? ic - a.in_w : -1;
+        double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
+        for (int s = 0; s < F; s++) {
+            const int j = s <= jbc ? jbc - s : s;
+            const int gc = ext_index(ic - j, a.in_w, a.mode);
+            double tl = 0.0, th = 0.0;  // axis -2 sums of input column gc at output row oh
+            for (int s2 = 0; s2 < F; s2++) {
+                const int j2 = s2 <= jbr ? jbr - s2 : s2;
+                const int gr = ext_index(ir - j2, a.in_h, a.mode);
+                const double v = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
+                tl += a.lo[j2] * v;
+                th += a.hi[j2] * v;
+            }
+            aa += a.lo[j] * tl; da += a.lo[j] * th;
+            ad += a.hi[j] * tl; dd += a.hi[j] * th;
+        }
+        const int k = plane % a.c;
+        const bool has_m = a.mults != nullptr;
+        const double mk = has_m ? a.mults[k] : 1.0;
+        int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+        const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        if (a.last) {
+            const int32_t qaa = quant(aa, mk, a.q, has_m);
+            co[(size_t)oh * a.enc_w + ow] = qaa;
+            amax = iabs_u(qaa);
+        } else {
+            a.ll_out[(size_t)plane * a.out_h * a.out_w + (size_t)oh * a.out_w + ow] = aa;
+        }
+        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
+        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
+        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
+        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((threadIdx.x & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
     }
 }
 
@@ -569,6 +632,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
+    a.ov_h = a.out_h;
+    a.ov_w = a.out_w;
     if (a.f32) {
         uint32_t ntf = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW32_TH - 1) / DW32_TH) * (uint32_t)planes;
         hipLaunchKernelGGL((k_dwt_level_f32<F, LOM, HIM>), dim3(ntf), dim3(DW_BLOCK), 0, st, a);
@@ -581,8 +646,14 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((k_dwt_march<F, LOM, HIM>), dim3(gx * gy * (uint32_t)planes), dim3(256), 0, st, a, gx, gy);
         return (int)hipGetLastError();
     }
+    // outputs summed in PyWavelets' overhang order (k_dwt_edge): 2o+1 >= N on an axis whose input is at least as long as
+    // the filter (constant-edge mode keeps ascending order; shorter inputs go through another loop of pywt's)
+    if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, a.in_h / 2);
+    if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, a.in_w / 2);
     uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
     hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
+    if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 // specialised for the zero-tap pattern of the known filter bank of that length, generic otherwise

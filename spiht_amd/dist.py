@@ -1,12 +1,142 @@
-"""Multi-GPU layout helpers (host logic only; no torch import here).
+"""Multi-GPU side of the path (no torch anywhere).
 
 The path shards across images and not within one: rank r of `world` owns a contiguous block of the
 batch, codes it on its own GPU, and the only exchange is a gather of fixed-capacity stream slots
-(`slot_stride` bytes per image) plus the per-image bit counts and start planes.  The collective itself is issued
-by the caller (`torch.distributed.all_gather_into_tensor` over RCCL in bench.py, gloo in the CPU tests); these
-helpers define who owns what and how the gathered buffers are read back.
+(`slot_stride` bytes per image) plus the per-image bit counts and start planes.  The collective is the library's
+own (`spiht_gather_streams`: ncclAllGather on RCCL, queued on the context's stream); `Comm` binds it.  The job's
+RCCL id travels from rank 0 to the others over a small TCP exchange on MASTER_ADDR (`exchange_id`) -- the launcher
+contract is torchrun's environment (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT), nothing of torch is
+imported.  The helpers below `Comm` define who owns what and how gathered buffers are read back.
 """
+import ctypes as C
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+_MAGIC = b"SPIHTID1"
+_PORT_SPAN = 16  # candidate ports MASTER_PORT+1 .. MASTER_PORT+_PORT_SPAN (MASTER_PORT itself is the launcher's store)
+
+
+def _recv_exact(sock, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the connection")
+        buf += chunk
+    return buf
+
+
+def exchange_id(rank, world, payload=None, addr=None, port=None, timeout=300.0):
+    """Rank 0's `payload` (bytes) to every rank; returns it.  Rank 0 listens on the first free port of
+    MASTER_PORT+1.. and serves world-1 peers; a peer tries the candidate ports in turn until one answers with the
+    handshake of THIS job (magic + world size), so a foreign service on a candidate port is skipped."""
+    if world == 1:
+        return payload
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
+    hello = _MAGIC + struct.pack("<II", world, 0)
+    deadline = time.time() + timeout
+    if rank == 0:
+        srv = None
+        for k in range(1, _PORT_SPAN + 1):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind(("", base + k))
+                s.listen(world)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise RuntimeError("no free port in %d..%d for the id exchange" % (base + 1, base + _PORT_SPAN))
+        served = 0
+        srv.settimeout(1.0)
+        try:
+            while served < world - 1:
+                if time.time() > deadline:
+                    raise TimeoutError("id exchange: %d of %d peers arrived" % (served, world - 1))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                with conn:
+                    conn.settimeout(5.0)
+                    try:
+                        if _recv_exact(conn, len(hello)) != hello:
+                            continue
+                        conn.sendall(_MAGIC + struct.pack("<I", len(payload)) + payload)
+                        served += 1
+                    except (OSError, ConnectionError):
+                        continue
+        finally:
+            srv.close()
+        return payload
+    while True:
+        for k in range(1, _PORT_SPAN + 1):
+            try:
+                with socket.create_connection((addr, base + k), timeout=2.0) as c:
+                    c.settimeout(5.0)
+                    c.sendall(hello)
+                    head = _recv_exact(c, len(_MAGIC) + 4)
+                    if head[:len(_MAGIC)] != _MAGIC:
+                        continue
+                    (n,) = struct.unpack("<I", head[len(_MAGIC):])
+                    return _recv_exact(c, n)
+            except (OSError, ConnectionError):
+                continue
+        if time.time() > deadline:
+            raise TimeoutError("id exchange: rank 0 not reachable on %s:%d..%d" % (addr, base + 1, base + _PORT_SPAN))
+        time.sleep(0.2)
+
+
+class Comm:
+    """The job's RCCL communicator (spiht_comm of include/spiht_hip.h) on one context's GPU."""
+
+    def __init__(self, ctx, rank=None, world=None):
+        from . import _lib
+        self._lib = _lib.lib()
+        self._check = _lib.check
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        ident = None
+        if self.rank == 0:
+            buf = (C.c_uint8 * 128)()
+            self._check(self._lib.spiht_comm_unique_id(buf))
+            ident = bytes(buf)
+        ident = exchange_id(self.rank, self.world, ident)
+        h = C.c_void_p()
+        self._check(self._lib.spiht_comm_create(ctx.handle, (C.c_uint8 * 128).from_buffer_copy(ident), self.world,
+                                                self.rank, C.byref(h)))
+        self.handle = h
+
+    def info(self):
+        w, r, v = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._lib.spiht_comm_info(self.handle, C.byref(w), C.byref(r), C.byref(v)))
+        return dict(world=w.value, rank=r.value, rccl_version=v.value)
+
+    def gather_streams(self, ctx, d_slots, d_nbits, d_max_n, B, slot_stride, d_all_slots, d_all_nbits, d_all_max_n):
+        """queue the all-gather on ctx's stream (device pointers as ints); does not block"""
+        vp = C.c_void_p
+        self._check(self._lib.spiht_gather_streams(ctx.handle, self.handle, vp(d_slots), vp(d_nbits), vp(d_max_n), int(B),
+                                                   int(slot_stride), vp(d_all_slots), vp(d_all_nbits), vp(d_all_max_n)))
+
+    def barrier(self, ctx):
+        self._check(self._lib.spiht_comm_barrier(ctx.handle, self.handle))
+
+    def max_over_ranks(self, ctx, value):
+        v = C.c_double(float(value))
+        self._check(self._lib.spiht_comm_allreduce_max_f64(ctx.handle, self.handle, C.byref(v)))
+        return v.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.spiht_comm_destroy(self.handle)
+            self.handle = None
 
 
 def partition(total, world, rank):

@@ -3,8 +3,9 @@
 Same names, argument meaning and return types:
     encode(x, ll_h, ll_w, max_bits) -> (bytes, int)                       lib.rs:24-32
     decode(data_u8, n, c, h, w, ll_h, ll_w) -> ndarray[int32, (c,h,w)]    lib.rs:35-42
-Both run on the GPU through libspiht_hip.so; there is no CPU path.
-`decode_with_metadata` (lib.rs:47-56) is not part of the accelerated hot path yet.
+    decode_with_metadata(data_u8, n, c, h, w, ll_h, ll_w, top_slice, other_slices)
+        -> (ndarray[int32, (c,h,w)], ndarray[int32, (8*len+1, 8)])        lib.rs:47-56
+All three run on the GPU through libspiht_hip.so; there is no CPU path.
 """
 import ctypes as C
 

@@ -161,29 +161,15 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
     bound = C.c_uint64()
     _lib.check(L.spiht_encode_bound(c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], 0x3FFFFFFF, max_bits,
                                     C.byref(bound)))
-    slot = max(int(bound.value), 4)
-    d_img = ctx.alloc(img.nbytes)
-    d_out = ctx.alloc(slot)
-    d_meta = ctx.alloc(16)
-    try:
-        ctx.upload(d_img, img)
-        _lib.check((L.spiht_encode_image_batch_f32 if f32 else L.spiht_encode_image_batch_f64)(
-            ctx.handle, C.c_void_p(d_img), 1, c, h, w, wid, mid, -1 if level is None else int(level),
-            float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(d_out), slot,
-            C.c_void_p(d_meta), C.c_void_p(d_meta + 8), None))
-        ctx.synchronize()  # the batched entry points only queue work; device-side guards report here
-        meta = np.zeros(2, dtype=np.uint64)
-        ctx.download(meta, d_meta)
-        nbits = int(meta[0])
-        max_n = int(meta[1]) & 0xFF
-        nbytes = (nbits + 7) // 8
-        out = np.empty(nbytes, dtype=np.uint8)
-        if nbytes:
-            ctx.download(out, d_out)
-    finally:
-        ctx.free(d_img)
-        ctx.free(d_out)
-        ctx.free(d_meta)
+    out = np.empty(max(int(bound.value), 4), dtype=np.uint8)
+    nbits, mn = C.c_uint64(), C.c_uint8()
+    # one C call: upload, DWT + quantise + pyramid + list coder, stream back (the context keeps its device buffers)
+    _lib.check((L.spiht_encode_image_host_f32 if f32 else L.spiht_encode_image_host_f64)(
+        ctx.handle, C.c_void_p(img.ctypes.data), c, h, w, wid, mid, -1 if level is None else int(level),
+        float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(out.ctypes.data), out.size,
+        C.byref(nbits), C.byref(mn)))
+    max_n = int(mn.value)
+    out = out[:(int(nbits.value) + 7) // 8]
 
     return EncodingResult(out.tobytes(), h, w, c, max_n, level)
 
@@ -191,12 +177,30 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
 def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
                  return_metadata: bool = False) -> Union[np.ndarray, Tuple[np.ndarray, np.ndarray]]:
     """wrapper:192-216"""
-    d = decode_rec_array(encoding_result, spiht_settings, return_metadata)
-    spiht_metadata = d.pop("spiht_metadata", None)
-    image = decode_from_rec_arr(**d, spiht_settings=spiht_settings)
     if return_metadata:
+        d = decode_rec_array(encoding_result, spiht_settings, return_metadata)
+        spiht_metadata = d.pop("spiht_metadata", None)
+        image = decode_from_rec_arr(**d, spiht_settings=spiht_settings)
         return image, spiht_metadata
-    return image
+    # decode_rec_array + decode_from_rec_arr (wrapper:218-281) as one C call: the coefficient array never leaves HBM
+    if encoding_result._encoding_version != ENCODER_DECODER_VERSION:
+        raise ValueError(encoding_result._encoding_version)
+    h, w, c, level = encoding_result.h, encoding_result.w, encoding_result.c, encoding_result.level
+    wid, mid = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(h, w, wid, level)
+    buf = spiht_rs._as_u8_vec(encoding_result.encoded_bytes)
+    n = spiht_rs._as_usize(encoding_result.max_n, "n")
+    if n > 255:
+        raise OverflowError("out of range integral type conversion attempted")
+    mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
+    out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
+    _lib.check(_lib.lib().spiht_decode_image_host_f64(
+        _lib.default_context().handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w, wid, mid,
+        -1 if level is None else int(level), float(spiht_settings.quantization_scale), mults_p,
+        C.c_void_p(out.ctypes.data)))
+    if spiht_settings.color_model is not None:
+        out = color_models.convert(out, spiht_settings.color_model, "RGB")
+    return out
 
 
 def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSettings, return_metadata: bool = False):
@@ -249,18 +253,9 @@ def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settin
     ctx = _lib.default_context()
     L = _lib.lib()
     out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
-    d_rec = ctx.alloc(rec.nbytes)
-    d_out = ctx.alloc(out.nbytes)
-    try:
-        ctx.upload(d_rec, rec)
-        _lib.check(L.spiht_dequant_idwt_batch_f64(ctx.handle, C.c_void_p(d_rec), 1, c, h, w, wid, mid,
-                                                  -1 if level is None else int(level),
-                                                  float(spiht_settings.quantization_scale), mults_p, C.c_void_p(d_out)))
-        ctx.synchronize()
-        ctx.download(out, d_out)
-    finally:
-        ctx.free(d_rec)
-        ctx.free(d_out)
+    _lib.check(L.spiht_dequant_idwt_host_f64(ctx.handle, C.c_void_p(rec.ctypes.data), c, h, w, wid, mid,
+                                             -1 if level is None else int(level),
+                                             float(spiht_settings.quantization_scale), mults_p, C.c_void_p(out.ctypes.data)))
     rec_image = out
     color_model = spiht_settings.color_model
     if color_model is not None:

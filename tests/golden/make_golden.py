@@ -13,6 +13,9 @@ seeded inputs and stores inputs + outputs as .npz fixtures next to this file.
                                                (int32 rec array -> pixels), geometry, filter banks
                                                -> wrapper_pywt.npz
 
+  part "blocky"  (python3.9, PyWavelets 1.1.1)  float64 coefficient arrays of piecewise-constant images, bit for bit
+                                               -> blocky_pywt.npz (pins the summation order at the right / bottom edge)
+
 usage:
   PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py loops
   PYTHONDONTWRITEBYTECODE=1 /opt/conda/bin/python3.9 -W ignore tests/golden/make_golden.py wrapper
@@ -270,5 +273,50 @@ def part_wrapper32():
     print("wrote wrapper32_pywt.npz:", len(cases), "cases; pywt", pywt.__version__, "numpy", np.__version__)
 
 
+def blocky_image(seed, c, H, W):
+    """piecewise-constant picture with a handful of grey levels (uint8 / 255): on such pixels many products
+    coefficient x q are integers up to the last bits of the sum, so the truncating quantiser sees the ORDER of the
+    additions (PyWavelets adds the taps that read the signal extension first on the right / bottom overhang)"""
+    rng = np.random.default_rng(seed)
+    levels = rng.choice(256, size=int(rng.integers(2, 6)), replace=False)
+    bh, bw = int(rng.integers(2, 9)), int(rng.integers(2, 9))
+    cells = rng.choice(levels, size=(c, (H + bh - 1) // bh, (W + bw - 1) // bw))
+    img = np.kron(cells, np.ones((bh, bw), dtype=np.int64))[:, :H, :W]
+    return img.astype(np.uint8) / 255
+
+
+def part_blocky():
+    """float64 packed coefficient arrays (every bit) and the int32 arrays handed to the Rust core, for blocky images of odd
+    and even sizes: pins the summation order of the forward transform at the right / bottom edge."""
+    import pywt
+    cases = []
+    rng = np.random.default_rng(99)
+    wvs = ["bior2.2", "bior2.2", "bior2.2", "bior4.4", "bior6.8"]
+    modes = ["reflect", "reflect", "symmetric", "reflect", "reflect", "periodic", "zero", "constant"]
+    for i in range(40):
+        H, W = int(rng.integers(17, 72)), int(rng.integers(17, 72))
+        wv = wvs[i % len(wvs)]
+        F = {"bior2.2": 6, "bior4.4": 10, "bior6.8": 18}[wv]
+        lv = 1 + i % 3
+        while lv > 1 and min(H, W) < F * 2 ** (lv - 1):  # every level's input at least as long as the filter
+            lv -= 1
+        cases.append((300 + i, 1 + i % 3, H, W, wv, lv, [50.0, 50.0, 10.0, 255.0][i % 4], modes[i % len(modes)]))
+    out = {"ncases": np.array(len(cases))}
+    for i, (seed, c, H, W, wv, lv, q, mode) in enumerate(cases):
+        img = blocky_image(seed, c, H, W)
+        arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wavelet=wv, level=lv, mode=mode), axes=(-2, -1))
+        assert arr.dtype == np.float64
+        p = "c%d_" % i
+        out[p + "meta"] = np.array([seed, c, H, W, lv])
+        out[p + "wavelet"] = np.array(wv)
+        out[p + "mode"] = np.array(mode)
+        out[p + "q"] = np.array(q)
+        out[p + "arr"] = arr
+        out[p + "quant"] = np.ascontiguousarray((arr * q).astype(np.int32))
+    np.savez_compressed(os.path.join(HERE, "blocky_pywt.npz"), **out)
+    print("wrote blocky_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
+
+
 if __name__ == "__main__":
-    {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32}[sys.argv[1]]()
+    {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32,
+     "blocky": part_blocky}[sys.argv[1]]()

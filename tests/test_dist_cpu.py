@@ -114,3 +114,39 @@ def test_two_rank_gloo_gather(total, oracle):
     res.sort()
     assert all(r[1] is True for r in res), res
     assert res[0][2] == res[1][2]  # both ranks hold the same gathered streams
+
+
+def _id_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        from spiht_amd.dist import exchange_id
+        payload = bytes(range(128)) if rank == 0 else None
+        got = exchange_id(rank, world, payload, addr="127.0.0.1", port=port, timeout=60)
+        q.put((rank, got == bytes(range(128))))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+def test_id_exchange_two_and_three_ranks():
+    """The host channel that carries rank 0's RCCL id to the other ranks (spiht_amd/dist.py:exchange_id): a TCP exchange
+    on MASTER_ADDR, ports MASTER_PORT+1..; late starters, a busy first port and world sizes 2 and 3."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    for world, order in ((2, (1, 0)), (3, (2, 0, 1))):
+        port = _free_port()
+        blocker = socket.socket()      # a foreign service on the first candidate port
+        try:
+            blocker.bind(("127.0.0.1", port + 1))
+            blocker.listen(1)
+        except OSError:
+            blocker = None
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_id_worker, args=(r, world, port, q)) for r in order]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+        if blocker is not None:
+            blocker.close()
+        assert res == [(r, True) for r in range(world)], res

@@ -35,3 +35,29 @@ def test_bench_line_contract(pipeline):
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == "Mpixels/s" and "sample" in c
     chk = d["check"]
     assert chk["nbits_all_equal_budget"] and chk["stream_bit_exact_vs_oracle"] and chk["decoded_image_bit_exact_vs_oracle"]
+    assert chk["images_checked_vs_oracle"] == 3 and chk["cycled_copies_equal"]  # every distinct image, not image 0 only
+    assert d["config"]["distinct_images_per_gpu"] == 3 and d["config"]["gather"] is None
+    sl = d["single_image_latency"]
+    assert sl["host_api_encode_ms"] > 0 and sl["host_api_decode_ms"] > 0 and sl["host_api_stream_equals_batch"]
+
+
+def test_bench_under_a_launcher_gathers_through_rccl():
+    """With the launcher's environment set (one rank here: a one-GPU box) bench.py takes the multi-GPU path: the
+    library's own RCCL communicator (spiht_comm_create), the stream gather queued on the list-coding stream
+    (spiht_gather_streams) and the decoder reading this rank's rows of the GATHERED buffers.  No torch is imported."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for pipeline in ("1", "0"):
+        p = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                            "--warmup", "1", "--batch", "4", "--cpu-sample", "0", "--pipeline", pipeline],
+                           cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert " torch" not in p.stderr  # -X importtime lists every imported module on stderr
+        d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["n_gpus"] == 1 and d["check"]["gather_rows_match"] is True
+        assert d["config"]["gather"]["world"] == 1 and d["config"]["gather"]["rccl_version"] > 0
+        assert d["check"]["nbits_all_equal_budget"] and d["cpu_baseline"] is None

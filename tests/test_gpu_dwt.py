@@ -81,6 +81,19 @@ def test_forward_matches_pywt_goldens_and_oracle(oracle):
         assert np.array_equal(got, oracle.quantize(arr, cs["q"], cs["mults"]))
 
 
+def test_forward_matches_pywt_on_blocky_images(oracle):
+    """The quantised coefficient arrays PyWavelets + the wrapper's arithmetic produce for piecewise-constant 8-bit
+    pictures (tests/golden/blocky_pywt.npz): the bottom / right overhang is summed in pywt's order (k_dwt_edge)."""
+    from test_oracle import blocky_cases
+    n = 0
+    for cs in blocky_cases():
+        got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        bad = np.argwhere(got != cs["quant"])
+        assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, len(bad), bad[:4])
+        n += 1
+    assert n == 40
+
+
 def test_inverse_matches_pywt_goldens_and_oracle(oracle):
     for cs in _cases():
         got = _gpu_idwt(cs["rec"][None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], cs["mults"])[0]

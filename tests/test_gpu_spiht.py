@@ -124,13 +124,74 @@ def test_prefix_truncation_and_pad_bits(oracle):
             _check_decode(oracle, d, n2, (c, h, w), lh, lw)
 
 
-def test_decode_arbitrary_bytes_even_ll(oracle):
-    """Any byte string is a valid input when the tree has no duplicated nodes (even LL)."""
+def test_decode_arbitrary_bytes(oracle):
+    """Any byte string is a valid input (lib.rs:38 hands every bit to the decoder).  On trees with duplicated nodes
+    (odd ll_h / ll_w) two or three list entries write the same cell, and for bytes no encoder produced
+    their operations differ: the cell must end as the reference's sequential writes leave it
+    (encoder_decoder.rs:352-451)."""
     rng = np.random.default_rng(5)
-    for (c, h, w, lh, lw) in [(1, 16, 16, 2, 2), (2, 24, 40, 4, 6)]:
-        for ln in [1, 3, 17, 200]:
-            d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
-            _check_decode(oracle, d, 9, (c, h, w), lh, lw)
+    for (c, h, w, lh, lw) in [(1, 16, 16, 2, 2), (2, 24, 40, 4, 6), (3, 13, 17, 3, 5), (2, 26, 38, 13, 19),
+                              (1, 23, 31, 5, 6), (2, 40, 37, 6, 9), (3, 64, 96, 3, 3)]:
+        for ln in [1, 3, 17, 200, 1500]:
+            for n in (9, 3, 0):
+                d = rng.integers(0, 256, ln, dtype=np.uint8).tobytes()
+                _check_decode(oracle, d, n, (c, h, w), lh, lw)
+        # streams dense in ones (many significance hits: duplicated cells get written by all their list entries)
+        for ln in [40, 600]:
+            d = (rng.integers(0, 256, ln, dtype=np.uint8) | rng.integers(0, 256, ln, dtype=np.uint8)).astype(np.uint8).tobytes()
+            _check_decode(oracle, d, 6, (c, h, w), lh, lw)
+
+
+def test_decode_bit_flipped_stream_odd_ll(oracle):
+    """A damaged encoder stream on the geometry class of BASELINE config 2 (ll 13x19, both odd): after the first flipped
+    bit the decoder walks a different path than the encoder did and the duplicated cells' list entries diverge."""
+    c, h, w, lh, lw = 3, 293, 501, 13, 19
+    x = synth_coeffs(42, c, h, w, lh, lw)
+    d, n = oracle.encode(x, lh, lw, 120000)
+    rng = np.random.default_rng(11)
+    for trial in range(6):
+        b = bytearray(d)
+        for pos in rng.integers(0, len(b) * 8, 1 + 3 * trial):
+            b[int(pos) >> 3] ^= 1 << (int(pos) & 7)
+        _check_decode(oracle, bytes(b), n, (c, h, w), lh, lw)
+        _check_decode(oracle, bytes(b[:len(b) // (trial + 1)]), n, (c, h, w), lh, lw)
+
+
+PYR_SHAPES = [(1, 16, 16, 2, 2), (3, 13, 17, 3, 5), (2, 26, 38, 13, 19), (1, 23, 31, 5, 6), (2, 40, 37, 6, 9),
+              (1, 64, 64, 2, 2), (3, 293, 501, 13, 19), (1, 533, 533, 20, 20)]
+
+
+@pytest.mark.parametrize("shape", PYR_SHAPES)
+def test_pyramid_matches_oracle(oracle, shape):
+    """The D / L significance pyramid (csrc/pyramid.hip) against the recursion it replaces, element by element:
+    is_set_sig / is_l_sig (encoder_decoder.rs:78-121) evaluated per node and per plane by the oracle.  Only nodes with
+    offspring carry a code (the others are never looked up)."""
+    import ctypes as C
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    c, h, w, lh, lw = shape
+    B = 2
+    xs = np.stack([synth_coeffs(77 + b, c, h, w, lh, lw) for b in range(B)])
+    xs[1, :, h // 2:, :] = 0            # empty sets: code 0
+    xs[1, 0, h - 1, w - 1] = -(1 << 20)  # a lone large value in the last row / column (unreachable when h or w is odd)
+    xs[1, 0, (h - 1) // 2, (w - 1) // 2] = 1 << 17
+    L, ctx, vp = _lib.lib(), _lib.default_context(), C.c_void_p
+    n = c * h * w
+    d_x = DeviceArray(ctx, (B, n), np.int32)
+    d_dm, d_lm, d_ma = DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B,), np.uint32)
+    d_x.upload(xs.reshape(B, n))
+    ctx.memset(d_dm.ptr, 0xEE, d_dm.nbytes)
+    ctx.memset(d_lm.ptr, 0xEE, d_lm.nbytes)
+    _lib.check(L.spiht_pyramid_batch_i32(ctx.handle, vp(d_x.ptr), B, c, h, w, lh, lw, vp(d_dm.ptr), vp(d_lm.ptr), vp(d_ma.ptr)))
+    ctx.synchronize()
+    dm, lm, ma = d_dm.download().reshape(B, c, h, w), d_lm.download().reshape(B, c, h, w), d_ma.download()
+    for b in range(B):
+        d_ref, l_ref, has = oracle.set_codes(xs[b], lh, lw)
+        assert int(ma[b]) == int(np.abs(xs[b].astype(np.int64)).max())
+        for name, got, ref in (("D", dm[b], d_ref), ("L", lm[b], l_ref)):
+            bad = np.argwhere((got != ref) & has)
+            assert len(bad) == 0, "%s code differs at %d nodes, first %s: got %d want %d" % (
+                name, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
 
 
 def test_golden_python_twin_inputs_rust_rule(oracle):
