@@ -1470,6 +1470,7 @@ extern "C" int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, in
     return SPIHT_OK;
 }
 
+#ifdef SPIHT_DIAG  // diagnostics of tools/corun*.py, not part of the product library (tools/build_variant.sh diag -DSPIHT_DIAG)
 // diagnostic: copy the device error/debug words (64 x uint32) to the host
 extern "C" int spiht_launch_spin(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, hipStream_t st);
 // diagnostic, not part of the ABI header: occupy the GPU with `blocks` idle workgroups for `ticks` clock ticks
@@ -1488,6 +1489,7 @@ extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
     HIPCHK(hipMemcpy(out64, ctx->err.p, 256, hipMemcpyDeviceToHost));
     return SPIHT_OK;
 }
+#endif  // SPIHT_DIAG
 
 // ------------------------------------------------------------------------------------------------
 // multi-GPU: the one exchange of the path -- an all-gather of the stream slots, bit counts and start planes between

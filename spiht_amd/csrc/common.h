@@ -135,8 +135,10 @@ struct DwtKArgs {
     int32_t last;          // coarsest level: LL is quantised into the packed array too
     int32_t planes;        // B*c (set by the launcher)
     int32_t f32;           // single-precision level (k_dwt_level_f32): `in` / `ll_out` then point to float arrays
-    int32_t ov_h, ov_w;    // first output row / column that hangs over the bottom / right end of the input AND is summed in
-                           // PyWavelets' overhang order (k_dwt_edge); out_h / out_w when there is none (set by the launcher)
+    int32_t ov_h, ov_w;    // first output row / column that hangs over the bottom / right end of the input far enough for
+                           // PyWavelets' overhang order to differ from ascending order; out_h / out_w: none (launcher)
+    int32_t et_x, et_y;    // first tile column / row holding such outputs: the tiles left of / above them run the kernel
+                           // instantiation without the overhang code, the others the one with it (launcher)
     const double *in;      // [planes, in_h, in_w]
     double *ll_out;        // [planes, out_h, out_w]
     int32_t *coeffs;       // [planes, enc_h, enc_w]

@@ -79,7 +79,10 @@ __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes).  LOM / HIM: bit j set = tap j of dec_lo / dec_hi is non-zero;
 // a zero tap contributes exactly nothing (0*x added to the running sum), so skipping it changes no bit and
 // removes a third (bior2.2) to a fifth of the float64 arithmetic.
-template <int F, uint32_t LOM, uint32_t HIM>
+// EDGE: the instantiation for the tiles that hold the bottom / right overhang outputs, which are summed in PyWavelets'
+// order (below); the interior tiles run the instantiation without that code (it costs the fast path 10 % when it is
+// merely present: measured).  The two launches cover the tile grid between them (DwtKArgs::et_*).
+template <int F, uint32_t LOM, uint32_t HIM, bool EDGE>
 __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
     constexpr int NR = 2 * DW_TH + F - 2;  // input rows needed
@@ -92,7 +95,18 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     __shared__ double s_hi[2][PS];
     __shared__ int s_row[NR];
     uint32_t tbx, tby, tbz;
-    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+    if (!EDGE) {
+        xcd_tile((uint32_t)a.et_x, (uint32_t)a.et_y, a.planes, tbx, tby, tbz);  // tiles left of et_x and above et_y
+    } else {
+        // the other tiles of a plane, numbered: the column strip right of et_x (all tile rows), then the rest of the
+        // bottom strip
+        const uint32_t gx = (a.out_w + DW_TW - 1) / DW_TW, gy = (a.out_h + DW_TH - 1) / DW_TH;
+        const uint32_t sw = gx - (uint32_t)a.et_x, ns = sw * gy, ne = ns + (uint32_t)a.et_x * (gy - (uint32_t)a.et_y);
+        uint32_t e, dummy;
+        xcd_tile(ne, 1, a.planes, e, dummy, tbz);
+        if (e < ns) { tbx = (uint32_t)a.et_x + e % sw; tby = e / sw; }
+        else { e -= ns; tbx = e % (uint32_t)a.et_x; tby = (uint32_t)a.et_y + e / (uint32_t)a.et_x; }
+    }
     const int plane = (int)tbz;
     const int oh0 = (int)tby * DW_TH, ow0 = (int)tbx * DW_TW;
     const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
@@ -125,6 +139,26 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
             s_lo[par][o * RS + hc] = sl;
             s_hi[par][o * RS + hc] = shh;
         }
+        // Bottom overhang, PyWavelets' order (downsampling_convolution): for an output that hangs over the end of the
+        // input (2o+1 >= N) the taps that read the signal extension come first, nearest first (tap 2o+1-N down to 0),
+        // then the others ascending.  Only the last row or two of a level differ in a bit from the ascending sums above
+        // (ov_h: set by the launcher), so only the bottom tile row comes here (a block-uniform branch); the samples are
+        // loaded again -- run-time tap order would turn x[] into scratch memory.
+        if (EDGE && oh0 + DW_TH > a.ov_h) {
+            for (int o = max(a.ov_h - oh0, 0); o < DW_TH && oh0 + o < a.out_h; o++) {
+                const int jb = 2 * (oh0 + o) + 1 - a.in_h;
+                double sl = 0.0, shh = 0.0;
+                for (int s2 = 0; s2 < F; s2++) {
+                    const int j = s2 <= jb ? jb - s2 : s2;
+                    const int gr = s_row[2 * o + F - 1 - j];
+                    const double v = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
+                    sl += a.lo[j] * v;
+                    shh += a.hi[j] * v;
+                }
+                s_lo[par][o * RS + hc] = sl;
+                s_hi[par][o * RS + hc] = shh;
+            }
+        }
     }
     __syncthreads();
 
@@ -150,85 +184,33 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
             if ((LOM >> j) & 1u) { aa += a.lo[j] * vl; da += a.lo[j] * vh; }
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }
+        if (EDGE && ow >= a.ov_w) {  // right overhang: the same order along this axis (the last column or two of a level)
+            const int jb = 2 * ow + 1 - a.in_w;
+            aa = 0.0; ad = 0.0; da = 0.0; dd = 0.0;
+            for (int s2 = 0; s2 < F; s2++) {
+                const int j = s2 <= jb ? jb - s2 : s2;
+                const double vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                const double vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
+                aa += a.lo[j] * vl; da += a.lo[j] * vh;
+                ad += a.hi[j] * vl; dd += a.hi[j] * vh;
+            }
+        }
         const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
-        // outputs on the bottom / right overhang are summed again in PyWavelets' order by k_dwt_edge, which overwrites
-        // them and accounts for their magnitude
-        const bool mine = oh < a.ov_h && ow < a.ov_w;
         if (a.last) {
             const int32_t qaa = quant(aa, mk, a.q, has_m);
             co[(size_t)oh * a.enc_w + ow] = qaa;
-            if (mine) amax = max(amax, iabs_u(qaa));
+            amax = max(amax, iabs_u(qaa));
         } else {
             llo[(size_t)oh * a.out_w + ow] = aa;
         }
         co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;                 // 'ad' top-right
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;               // 'da' bottom-left
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
-        if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
-    }
-    if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
-    }
-}
-
-// ---- the bottom / right overhang of a float64 level, in PyWavelets' summation order -----------------------------
-// pywt's downsampling_convolution adds the taps in ascending order -- except for the outputs that hang over the end
-// of the input (2o+1 >= N, the last F/2 or so output rows and columns of a level): there the taps that read the signal
-// extension come first, nearest first (filter index 2o+1-N down to 0), then the others ascending.  The sums differ in
-// the last bits, and on 8-bit pictures with flat areas (coefficient x q exactly an integer) the truncating quantiser
-// turns that into +-1 (tests/golden/blocky_pywt.npz).  k_dwt_level keeps its compile-time ascending order everywhere;
-// this kernel then recomputes just those outputs, one thread each, straight from global memory (F*F loads per output,
-// a few thousand outputs per plane), and overwrites them.  grid: (ceil(outputs / 256), planes).
-__global__ __launch_bounds__(256) void k_dwt_edge(DwtKArgs a) {
-    const int F = a.F;
-    const int nr = a.out_h - a.ov_h, nc = a.out_w - a.ov_w;        // overhang rows / columns
-    const int nA = nr * a.out_w, total = nA + a.ov_h * nc;          // all columns of the overhang rows + the rest of the columns
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int plane = blockIdx.y;
-    uint32_t amax = 0;
-    if (t < total) {
-        int oh, ow;
-        if (t < nA) { oh = a.ov_h + t / a.out_w; ow = t % a.out_w; }
-        else { const int u = t - nA; oh = u / nc; ow = a.ov_w + u % nc; }
-        const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
-        const int ir = 2 * oh + 1, ic = 2 * ow + 1;
-        const int jbr = oh >= a.ov_h ? ir - a.in_h : -1, jbc = ow >= a.ov_w ? ic - a.in_w : -1;
-        double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
-        for (int s = 0; s < F; s++) {
-            const int j = s <= jbc ? jbc - s : s;
-            const int gc = ext_index(ic - j, a.in_w, a.mode);
-            double tl = 0.0, th = 0.0;  // axis -2 sums of input column gc at output row oh
-            for (int s2 = 0; s2 < F; s2++) {
-                const int j2 = s2 <= jbr ? jbr - s2 : s2;
-                const int gr = ext_index(ir - j2, a.in_h, a.mode);
-                const double v = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
-                tl += a.lo[j2] * v;
-                th += a.hi[j2] * v;
-            }
-            aa += a.lo[j] * tl; da += a.lo[j] * th;
-            ad += a.hi[j] * tl; dd += a.hi[j] * th;
-        }
-        const int k = plane % a.c;
-        const bool has_m = a.mults != nullptr;
-        const double mk = has_m ? a.mults[k] : 1.0;
-        int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
-        const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
-        if (a.last) {
-            const int32_t qaa = quant(aa, mk, a.q, has_m);
-            co[(size_t)oh * a.enc_w + ow] = qaa;
-            amax = iabs_u(qaa);
-        } else {
-            a.ll_out[(size_t)plane * a.out_h * a.out_w + (size_t)oh * a.out_w + ow] = aa;
-        }
-        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
-        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
-        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
         amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((threadIdx.x & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
     }
 }
 
@@ -360,6 +342,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
     }
 }
 
+#ifdef SPIHT_DIAG  // experiment kept for reference (equal at best), not in the product build
 // ---- row-marching variant of the forward level ------------------------------------------------------------------
 // A workgroup owns a strip of MW_SW output columns and marches down MW_ROWS output rows: thread = input column keeps
 // the F rows its column filter needs in registers (two new rows per step, prefetched MW_PF steps ahead, so every
@@ -461,6 +444,7 @@ __global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint
         if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
     }
 }
+#endif  // SPIHT_DIAG
 
 // zero the padding cells of coeffs_to_array: per level the strip below 'ad' and the strip right of 'da'.
 // grid: (blocks, nrects, planes)
@@ -545,9 +529,16 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
         const int bi = kh0 + r, bj = kw0 + cidx;
         double vaa = 0.0, vad = 0.0, vda = 0.0, vdd = 0.0;
         if (bi < a.band_h && bj < a.band_w) {
+#ifdef IDWT_EXP_SKIP  // timing experiment only (wrong results): what the inverse transform costs without its detail-band reads
+            const bool skp = a.band_h > IDWT_EXP_SKIP;
+            const int32_t rad = skp ? 0 : rec[(size_t)bi * a.enc_w + a.off_w + bj];
+            const int32_t rda = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
+            const int32_t rdd = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+#else
             const int32_t rad = rec[(size_t)bi * a.enc_w + a.off_w + bj];
             const int32_t rda = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
             const int32_t rdd = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+#endif
             if (a.first) {
                 const int32_t raa = rec[(size_t)bi * a.enc_w + bj];
                 vaa = (raa == 0 && zero_ok) ? 0.0 : dequant(raa, mk, a.q, has_m);
@@ -639,6 +630,7 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((k_dwt_level_f32<F, LOM, HIM>), dim3(ntf), dim3(DW_BLOCK), 0, st, a);
         return (int)hipGetLastError();
     }
+#ifdef SPIHT_DIAG
     static const int use_march = [] { const char *e = getenv("SPIHT_DWT_MARCH"); return e ? atoi(e) : 0; }();
     if (use_march) {
         constexpr int SW = (256 - (F - 2)) / 2;
@@ -646,14 +638,23 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((k_dwt_march<F, LOM, HIM>), dim3(gx * gy * (uint32_t)planes), dim3(256), 0, st, a, gx, gy);
         return (int)hipGetLastError();
     }
-    // outputs summed in PyWavelets' overhang order (k_dwt_edge): 2o+1 >= N on an axis whose input is at least as long as
-    // the filter (constant-edge mode keeps ascending order; shorter inputs go through another loop of pywt's)
-    if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, a.in_h / 2);
-    if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, a.in_w / 2);
-    uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
-    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
-    const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
-    if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
+#endif
+    // Outputs summed in PyWavelets' overhang order: those with jb = 2o+1-N >= 0 on an axis whose input is at least as
+    // long as the filter (constant-edge mode keeps ascending order; shorter inputs go through another loop of pywt's).
+    // The order is tap jb, jb-1, ..., 0, jb+1, ...: with z leading taps that are zero in both filters it gives the same
+    // bits as ascending order until jb >= z+2 (a zero tap adds nothing and the first two non-zero terms commute).
+    int z = 0;
+    while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
+    if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
+    if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
+    const int gx = (a.out_w + DW_TW - 1) / DW_TW, gy = (a.out_h + DW_TH - 1) / DW_TH;
+    a.et_x = min(gx, a.ov_w / DW_TW);  // first tile column / row that holds such outputs (gx / gy: none)
+    a.et_y = min(gy, a.ov_h / DW_TH);
+    if (a.ov_w >= a.out_w) a.et_x = gx;
+    if (a.ov_h >= a.out_h) a.et_y = gy;
+    const uint32_t n_in = (uint32_t)a.et_x * (uint32_t)a.et_y, n_edge = (uint32_t)gx * (uint32_t)gy - n_in;
+    if (n_in) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(n_in * (uint32_t)planes), dim3(DW_BLOCK), 0, st, a);
+    if (n_edge) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(n_edge * (uint32_t)planes), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
 }
 // specialised for the zero-tap pattern of the known filter bank of that length, generic otherwise

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: does the forward / inverse DWT slow down merely because another kernel's workgroups are RESIDENT on the
+"""Diagnostic (needs a diagnostic build: tools/build_variant.sh diag -DSPIHT_DIAG, then SPIHT_HIP_LIB=build/var_diag/spiht_amd/libspiht_hip.so): does the forward / inverse DWT slow down merely because another kernel's workgroups are RESIDENT on the
 CUs (no memory traffic at all)?  python tools/corun_spin.py [batch]"""
 import ctypes as C
 import os

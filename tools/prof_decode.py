@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: where the decoder's sequencer wavefront spends its time (needs the -DDEC_PROF build:
+"""Diagnostic (needs a diagnostic build: tools/build_variant.sh prof -DSPIHT_DIAG -DDEC_PROF, then SPIHT_HIP_LIB=build/var_prof/spiht_amd/libspiht_hip.so): where the decoder's sequencer wavefront spends its time (needs the -DDEC_PROF build:
 SPIHT_HIP_LIB=spiht_amd/libspiht_hip_prof.so python tools/prof_decode.py [batch])."""
 import ctypes as C
 import os
