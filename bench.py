@@ -151,6 +151,12 @@ def main():
                          "inverse DWT of step i-1) run on one context while step i is list-coded on another "
                          "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  "
                          "0: every step runs its stages back to back on one stream, each kernel with the whole GPU")
+    ap.add_argument("--pair", choices=["forward", "inverse"], default="inverse",
+                    help="what the list decoder of step i shares the GPU with in the pipelined schedule: the forward transform of "
+                         "step i+1 or the inverse transform of step i-1 (default; OverlappedCodec)")
+    ap.add_argument("--split-inverse", type=int, default=0, help="experiment: coarse inverse levels on the list-coding stream")
+    ap.add_argument("--l-priority", type=int, default=0, help="experiment: stream priority of the list-coding contexts")
+    ap.add_argument("--e-first", type=int, default=0, help="experiment: encoder kernel queued before the unscatter")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -250,7 +256,8 @@ def main():
         # list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).  The
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
         from spiht_amd.batch import OverlappedCodec
-        pipe = OverlappedCodec(codec, B)
+        pipe = OverlappedCodec(codec, B, pair=args.pair, split_inverse=bool(args.split_inverse), l_priority=args.l_priority,
+                               e_first=bool(args.e_first))
         ctxs.extend(pipe.Ls)
 
     def step():

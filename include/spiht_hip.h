@@ -48,6 +48,9 @@ int spiht_abi_version(void);
 /* One context per (process, GPU): device id, streams, scratch.  Thread-safe per context
  * (calls on one context are serialised by an internal mutex); no globals survive a call. */
 int spiht_ctx_create(int device, spiht_ctx **out);
+/* priority > 0: the context's stream gets the device's highest stream priority (its workgroups are placed first when
+ * kernels of several contexts wait for room on the CUs); 0: as spiht_ctx_create. */
+int spiht_ctx_create_priority(int device, int priority, spiht_ctx **out);
 void spiht_ctx_destroy(spiht_ctx *ctx);
 /* Block until everything queued on the context's stream has finished. */
 int spiht_ctx_synchronize(spiht_ctx *ctx);
@@ -219,6 +222,17 @@ int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t
                                  const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
                                  int64_t ll_w, int32_t *d_out_zeroed);
 int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w);
+/* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels
+ * (level .. 2: a quarter of the bytes) into d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] float64 -- the approximation level 1
+ * starts from; spiht_idwt_approx_shape gives its size -- and level 1 from d_rec + d_approx to the pixels.  With fewer than
+ * two levels the coarse call does nothing and level 1 does everything.  Same bits as the one-call form. */
+int spiht_idwt_coarse_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H, int64_t W,
+                                int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                double *d_approx);
+int spiht_idwt_level1_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const double *d_approx, int64_t B, int64_t c,
+                                int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                const double *channel_mults, double *d_img_out);
+int spiht_idwt_approx_shape(int64_t H, int64_t W, int wavelet, int level, int64_t *a_h, int64_t *a_w);
 
 /* Colour model change on the device (the reference converts on the host through colour-science, color_models.py:6-13,
  * called from spiht_wrapper.py:158-160 and :278-279): B three-channel float64 images [B,3,npix]; per pixel
@@ -226,6 +240,14 @@ int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, i
  * back the inverses with 1/0.43.  A, M: row-major 3x3 host arrays.  d_out may equal d_in.  Asynchronous. */
 int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, int64_t B, int64_t npix, const double *A,
                            const double *M, double p);
+/* The colour model of the coded picture as a property of the context (spiht_wrapper.py:158-160, :278-279: RGB -> model
+ * before the transform, model -> RGB after the inverse transform), fused into the transform: while set, every image-level
+ * entry point of the context takes and returns RGB pixels of 3-channel float64 images and codes them in the other model --
+ * the forward level-1 kernel converts on its loads (w = M_f * spow(A_f * u, p_f)), the inverse level-1 kernel on its
+ * stores (A_i, M_i, p_i); the converted picture never exists in memory.  Same bits as spiht_color3_batch_f64 followed by
+ * the plain transform.  A_f == NULL clears the setting.  Images with other channel counts are coded as they are. */
+int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const double *M_f, double p_f, const double *A_i,
+                         const double *M_i, double p_i);
 
 /* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
  * counts the decoder takes, without a host round trip. */

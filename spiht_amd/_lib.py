@@ -32,7 +32,8 @@ _lib_lock = threading.Lock()
 
 # every symbol include/spiht_hip.h declares
 SYMBOLS = [
-    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_destroy",
+    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_create_priority",
+    "spiht_ctx_destroy",
     "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_event_create", "spiht_event_destroy", "spiht_event_record",
     "spiht_ctx_wait_event", "spiht_ctx_stream", "spiht_dwt_pyramid_batch_f64", "spiht_encode_lists_batch_i32",
     "spiht_decode_lists_batch_i32", "spiht_unscatter_lists_batch_i32", "spiht_ctx_set_timing", "spiht_ctx_reset_timing", "spiht_ctx_num_stages",
@@ -40,8 +41,9 @@ SYMBOLS = [
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
     "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
-    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
+    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset", "spiht_dev_copy",
+    "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_approx_shape",
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
@@ -69,6 +71,7 @@ def lib():
         L.spiht_strerror.argtypes = [i32]
         L.spiht_last_hip_error.restype = C.c_char_p
         L.spiht_ctx_create.argtypes = [i32, C.POINTER(vp)]
+        L.spiht_ctx_create_priority.argtypes = [i32, i32, C.POINTER(vp)]
         L.spiht_ctx_destroy.argtypes = [vp]
         L.spiht_ctx_destroy.restype = None
         L.spiht_ctx_synchronize.argtypes = [vp]
@@ -84,6 +87,7 @@ def lib():
         L.spiht_decode_lists_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
         L.spiht_unscatter_lists_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64]
         L.spiht_color3_batch_f64.argtypes = [vp, vp, vp, i64, i64, vp, vp, C.c_double]
+        L.spiht_ctx_set_color3.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_double]
         L.spiht_ctx_set_timing.argtypes = [vp, i32]
         L.spiht_ctx_reset_timing.argtypes = [vp]
         L.spiht_ctx_stage_name.restype = C.c_char_p
@@ -115,6 +119,9 @@ def lib():
         L.spiht_dev_download.argtypes = [vp, vp, vp, u64]
         L.spiht_dev_memset.argtypes = [vp, vp, i32, u64]
         L.spiht_dev_copy.argtypes = [vp, vp, vp, u64]
+        L.spiht_idwt_coarse_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_idwt_level1_batch_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_idwt_approx_shape.argtypes = [i64, i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
         L.spiht_encode_image_host_f64.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, vp, u64,
                                                   C.POINTER(u64), C.POINTER(u8)]
         L.spiht_encode_image_host_f32.argtypes = L.spiht_encode_image_host_f64.argtypes
@@ -152,10 +159,10 @@ def check(status):
 class Context:
     """One spiht_ctx (device id, stream, scratch).  Created lazily, one per device."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
         self._lib = lib()
         h = C.c_void_p()
-        check(self._lib.spiht_ctx_create(int(device), C.byref(h)))
+        check(self._lib.spiht_ctx_create_priority(int(device), int(priority), C.byref(h)))
         self.handle = h
         self.device = int(device)
 

@@ -52,10 +52,9 @@ class DeviceArray:
 class BatchCodec:
     """encode/decode B images [B,c,H,W] (float64) at a fixed bit budget.
 
-    settings / level / max_bits have the meaning of spiht_wrapper.encode_image.  The host-array calls (encode,
-    decode, decode_prefixes) apply settings.color_model on the device (color_models.device_convert, an elementwise
-    kernel before the transform / after the inverse transform); the raw device-pointer calls take and return pixels
-    in the coded colour model."""
+    settings / level / max_bits have the meaning of spiht_wrapper.encode_image, settings.color_model included: pixels
+    go in and come out as RGB, the change to and from the coded colour model happens inside level 1 of the transforms
+    (color_models.fused; 3-channel float64 images)."""
 
     def __init__(self, c, H, W, settings=None, level=None, max_bits=None, ctx=None, pixel_dtype=np.float64):
         # pixel_dtype float32: the encoder side runs PyWavelets' single-precision arithmetic (what the reference does
@@ -74,21 +73,34 @@ class BatchCodec:
                                              self.geom["ll_w"], 0x3FFFFFFF, self.max_bits, C.byref(bound)))
         self.slot_stride = max(int(bound.value), 4)
         self._lv = -1 if level is None else int(level)
+        if self.settings.color_model not in (None, "RGB"):
+            if self.settings.color_model not in color_models.SUPPORTED_MODELS:
+                raise ValueError(f'{self.settings.color_model} is not a supported color model. '
+                                 f'Supported models are {color_models.SUPPORTED_MODELS}')
+            if self.c != 3:
+                raise ValueError("colour conversion needs 3 channels")
+            if self.pixel_dtype != np.float64:
+                raise ValueError("colour conversion on the device takes float64 pixels")
+
+    def _color(self):
+        return color_models.fused(self.ctx, self.settings.color_model)
 
     # ---- raw device-pointer API (ints) -------------------------------------------------------
     def encode_device(self, d_img, B, d_out, d_nbits, d_max_n, d_coeffs=None):
         fn = self.L.spiht_encode_image_batch_f32 if self.pixel_dtype == np.float32 else self.L.spiht_encode_image_batch_f64
-        _lib.check(fn(
-            self.ctx.handle, C.c_void_p(d_img), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
-            float(self.settings.quantization_scale), self._mults_p, self.max_bits, C.c_void_p(d_out),
-            self.slot_stride, C.c_void_p(d_nbits), C.c_void_p(d_max_n), C.c_void_p(d_coeffs) if d_coeffs else None))
+        with self._color():
+            _lib.check(fn(
+                self.ctx.handle, C.c_void_p(d_img), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
+                float(self.settings.quantization_scale), self._mults_p, self.max_bits, C.c_void_p(d_out),
+                self.slot_stride, C.c_void_p(d_nbits), C.c_void_p(d_max_n), C.c_void_p(d_coeffs) if d_coeffs else None))
 
     def decode_device(self, d_data, d_nbytes, d_max_n, B, d_img_out, d_rec=None, slot_stride=None):
-        _lib.check(self.L.spiht_decode_image_batch_f64(
-            self.ctx.handle, C.c_void_p(d_data), self.slot_stride if slot_stride is None else int(slot_stride),
-            C.c_void_p(d_nbytes), C.c_void_p(d_max_n), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
-            float(self.settings.quantization_scale), self._mults_p, C.c_void_p(d_img_out),
-            C.c_void_p(d_rec) if d_rec else None))
+        with self._color():
+            _lib.check(self.L.spiht_decode_image_batch_f64(
+                self.ctx.handle, C.c_void_p(d_data), self.slot_stride if slot_stride is None else int(slot_stride),
+                C.c_void_p(d_nbytes), C.c_void_p(d_max_n), int(B), self.c, self.H, self.W, self.wid, self.mid, self._lv,
+                float(self.settings.quantization_scale), self._mults_p, C.c_void_p(d_img_out),
+                C.c_void_p(d_rec) if d_rec else None))
 
     def nbits_to_nbytes(self, d_nbits, B, d_nbytes):
         _lib.check(self.L.spiht_nbits_to_nbytes(self.ctx.handle, C.c_void_p(d_nbits), int(B), C.c_void_p(d_nbytes)))
@@ -106,12 +118,6 @@ class BatchCodec:
         d_maxn = DeviceArray(ctx, (B,), np.uint8)
         try:
             d_img.upload(images)
-            if self.settings.color_model is not None:  # wrapper:158-160
-                if self.pixel_dtype != np.float64:
-                    raise ValueError("colour conversion on the device takes float64 pixels")
-                if self.c != 3:
-                    raise ValueError("colour conversion needs 3 channels")
-                color_models.device_convert(ctx, d_img.ptr, B, self.H * self.W, 'RGB', self.settings.color_model)
             self.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
             ctx.synchronize()
             out, nbits, maxn = d_out.download(), d_nbits.download(), d_maxn.download()
@@ -140,11 +146,6 @@ class BatchCodec:
             d_nbytes.upload(nbytes)
             d_maxn.upload(maxn)
             self.decode_device(d_data.ptr, d_nbytes.ptr, d_maxn.ptr, B, d_img.ptr, slot_stride=stride)
-            if self.settings.color_model is not None:  # wrapper:278-279
-                if self.c != 3:
-                    raise ValueError("colour conversion needs 3 channels")
-                color_models.device_convert(ctx, d_img.ptr, B, self.geom["rec_h"] * self.geom["rec_w"],
-                                            self.settings.color_model, 'RGB')
             ctx.synchronize()
             return d_img.download()
         finally:
@@ -165,25 +166,41 @@ class OverlappedCodec:
 
     The transform / pyramid / inverse-transform passes are HBM-bound; the list coder is latency-bound and leaves the
     HBM idle.  Context H runs the former, contexts L0 / L1 (alternating by batch) the latter, ordered with events only
-    (the host never blocks), so while a batch is list-coded, H already transforms the next one and inverse-transforms
-    the previous one:
+    (the host never blocks):
 
-        H:  A(i)               [X(i-1) done] I(i-1)   A(i+1)                 [X(i) done] I(i) ...
-        L:  [A(i), I(i-2) done] U(i-2) E(i) X(i)              [A(i+1), I(i-1) done] U(i-1) E(i+1) X(i+1) ...
+        H:  [X(i-1) done] I(i-1)         A(i+1)                  [X(i) done] I(i)          A(i+2) ...
+        L:  [A(i), X(i-1) done] U E(i)   [I(i-1) done] X(i)      [A(i+1), X(i) done] U E(i+1)   [I(i) done] X(i+1) ...
 
     A = DWT + quantise + pyramid, E / X = encoder / decoder list kernels, I = dequantise + inverse DWT, U = put the
     zeros back into the coefficient array X(i-2) scattered into (spiht_unscatter_lists_batch_i32: through the
     decoder's lists, which is why each of the two arrays has its own list-coding context) -- a full zero-fill per
     batch would add 6.6 GB of writes to the HBM-bound side.  E(i+1) is ordered after X(i), so list kernels never run
-    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).  Results are
-    bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder output are
-    double-buffered.  `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook
-    for the stream gather of a multi-GPU job."""
+    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).
 
-    def __init__(self, codec, B, ctx_l=None):
+    What shares the GPU with what is chosen from measurements.  Resident decoder workgroups (12
+    wavefronts, 96 VGPRs) leave an HBM-bound kernel three instead of six or seven workgroups per CU.  The forward
+    transform lives with that -- its threads keep 28 loads in flight each: X and A side by side take 11.5 ms each
+    (7.9 and 7.8 alone) -- the inverse transform does not (level 1: 8.6 instead of 4.0 ms, and it still slows the decoder
+    to 10.1).  `pair="forward"` therefore holds the decoder X(i) back until the inverse transform of the previous
+    batch has finished: it then runs beside A(i+1), and I(i-1) meets only the short encoder kernel.  Measured: no better
+    (20.6 ms per step against 20.2 for `pair="inverse"`, X(i) right behind E(i) and beside I(i-1), which the diagram above
+    does NOT show: there X(i) follows E(i) directly and A runs mostly alone) -- whichever transform shares the GPU with
+    the decoder takes twice its time.  `pair="inverse"` is the default.
+
+    Results are bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder
+    output are double-buffered.  `split_inverse` queues the coarse levels of the inverse transform (level .. 2) behind
+    the decoder on the list-coding stream instead (measured: no gain, kept for experiments).  `between` (optional
+    callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream gather of a multi-GPU job."""
+
+    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False):
         self.codec, self.B = codec, int(B)
+        if pair not in ("forward", "inverse"):
+            raise ValueError("pair must be 'forward' or 'inverse'")
+        self.pair = pair
         self.H = codec.ctx
-        self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device), _lib.Context(self.H.device)]
+        self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device, l_priority),
+                   _lib.Context(self.H.device, l_priority)]
+        self.e_first = bool(e_first)  # experiment: encoder kernel queued before the unscatter
         self.L = self.Ls[0]
         g = codec.geom
         n = codec.c * g["enc_h"] * g["enc_w"]
@@ -192,6 +209,10 @@ class OverlappedCodec:
         self.coeffs, self.rec = mk((B, n), np.int32), mk((B, n), np.int32)
         self.dmsb, self.lmsb = mk((B, n), np.uint8), mk((B, n), np.uint8)
         self.maxabs = mk((B,), np.uint32)
+        ah, aw = C.c_int64(), C.c_int64()
+        _lib.check(codec.L.spiht_idwt_approx_shape(codec.H, codec.W, codec.wid, codec._lv, C.byref(ah), C.byref(aw)))
+        self.split = ah.value > 0 and split_inverse  # two levels or more: coarse levels on the list-coding stream
+        self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if self.split else [None, None]
         for r in self.rec:  # zero once; from then on U keeps them zero
             self.H.memset(r.ptr, 0, r.nbytes)
         self.H.synchronize()
@@ -208,9 +229,15 @@ class OverlappedCodec:
     def _idwt(self, s, d_img_out):
         cd = self.codec
         self.H.wait_event(self.ev_d[s])
-        _lib.check(cd.L.spiht_dequant_idwt_batch_f64(
-            self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
-            float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
+        with cd._color():  # (the colour setting of H is put on around each transform call: H may serve other codecs too)
+            if self.split:
+                _lib.check(cd.L.spiht_idwt_level1_batch_f64(
+                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr), self.B, cd.c, cd.H, cd.W,
+                    cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
+            else:
+                _lib.check(cd.L.spiht_dequant_idwt_batch_f64(
+                    self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
+                    float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
         self.H.record(self.ev_i[s])
 
     def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None, dec_src=None):
@@ -223,9 +250,10 @@ class OverlappedCodec:
         vp = C.c_void_p
         q = float(cd.settings.quantization_scale)
         # H: front half of the encoder
-        _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
-            self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
-            vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
+        with cd._color():
+            _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
+                self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
+                vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
         self.H.record(self.ev_a[s])
         # L: zeros back into the array batch i-2 was decoded into, once its inverse transform (queued on H by the
         # previous submit) has read it ...
@@ -234,25 +262,38 @@ class OverlappedCodec:
         if self.used[s ^ 1]:
             Lc.wait_event(self.ev_d[s ^ 1])
         Lc.wait_event(self.ev_a[s])
-        if self.used[s]:
-            Lc.wait_event(self.ev_i[s])
-            _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
+        def unscatter():
+            if self.used[s]:
+                Lc.wait_event(self.ev_i[s])
+                _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
+        if not self.e_first:
+            unscatter()
         # ... and list coding, after the previous batch's decoder on the other context
         _lib.check(cd.L.spiht_encode_lists_batch_i32(
             Lc.handle, vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr), B,
             cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], cd.max_bits, vp(d_out), cd.slot_stride, vp(d_nbits),
             vp(d_max_n)))
+        if self.e_first:
+            unscatter()
         if between is not None:
             between(Lc)
+        if self.pair == "forward" and self._pending is not None:
+            # the previous batch's inverse transform goes on H now (behind A(i)), and this batch's decoder waits for it
+            self._idwt(*self._pending)
+            Lc.wait_event(self.ev_i[self._pending[0]])
+            self._pending = None
         x_out, x_nbits, x_max_n = dec_src if dec_src is not None else (d_out, d_nbits, d_max_n)
         _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(x_nbits), B, vp(d_nbytes)))
         _lib.check(cd.L.spiht_decode_lists_batch_i32(
             Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, g["enc_h"], g["enc_w"],
             g["ll_h"], g["ll_w"], vp(self.rec[s].ptr)))
+        if self.split:  # the coarse levels of this batch's inverse transform, behind its decoder
+            _lib.check(cd.L.spiht_idwt_coarse_batch_f64(
+                Lc.handle, vp(self.rec[s].ptr), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
+                vp(self.approx[s].ptr)))
         Lc.record(self.ev_d[s])
         self.used[s] = True
-        # H: back half of the previous batch's decoder.  (Ordering X(i) after I(i-1) instead, so that the inverse
-        # transform runs alone, was measured: the forward DWT then runs beside the decoder and takes twice as long.)
+        # H: back half of the previous batch's decoder (pair="inverse": beside this batch's decoder)
         if self._pending is not None:
             self._idwt(*self._pending)
         self._pending = (s, d_img_out)

@@ -84,6 +84,9 @@ struct spiht_ctx {
     DevBuf trace, meta;  // decode_with_metadata
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
+    // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
+    bool color_on = false;
+    Color3 col_fwd, col_inv;
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -320,7 +323,11 @@ extern "C" const char *spiht_strerror(int s) {
 extern "C" const char *spiht_last_hip_error(void) { return g_hip_err.c_str(); }
 extern "C" int spiht_abi_version(void) { return 1; }
 
-extern "C" int spiht_ctx_create(int device, spiht_ctx **out) {
+extern "C" int spiht_ctx_create(int device, spiht_ctx **out) { return spiht_ctx_create_priority(device, 0, out); }
+
+// priority > 0: the context's stream is created with the device's highest stream priority -- its workgroups are placed
+// before those of normal streams when both wait for room on the CUs (the list-coding contexts of a pipelined schedule)
+extern "C" int spiht_ctx_create_priority(int device, int priority, spiht_ctx **out) {
     if (!out) return SPIHT_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
@@ -334,7 +341,14 @@ extern "C" int spiht_ctx_create(int device, spiht_ctx **out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e;
+    if (priority > 0) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, greatest);
+    } else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) {
         g_hip_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
         delete ctx;
@@ -912,8 +926,16 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         for (int l = 1; l <= ig.L; l++)
             if (ig.hs[l - 1] < wv.F || ig.ws[l - 1] < wv.F) return SPIHT_ERR_ARG;
     }
+    const bool color = ctx->color_on && c == 3;
+    if (color && f32) return SPIHT_ERR_ARG;  // the colour model change is float64 (as colour-science's)
     if (ig.L == 0) {
         StageTimer t(ctx, ST_DWT_REST);
+        if (color) {  // no transform level to carry the colour model change: a pass of its own
+            CHK(ensure(ctx, ctx->a0, (size_t)planes * plane_out * 8));
+            LAUNCHCHK(spiht_launch_color3(d_img, (double *)ctx->a0.p, planes / 3, plane_out, ctx->col_fwd.A, ctx->col_fwd.M,
+                                          ctx->col_fwd.p, ctx->stream));
+            d_img = (const double *)ctx->a0.p;
+        }
         LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, d_maxabs, ctx->stream));
         return SPIHT_OK;
     }
@@ -946,6 +968,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         a.mults = d_mults;
         a.maxabs = d_maxabs;
         a.q = q;
+        if (color && l == 1) { a.color = 1; a.col = ctx->col_fwd; }
         memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
         memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
         {
@@ -958,25 +981,34 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
 }
 
 // packed int32 array -> pixels [planes, rec_H, rec_W]
+// l_hi .. l_lo: the levels to run, coarsest first (ig.L .. 1 = all).  A run that stops above level 1 leaves its last
+// approximation in d_out ([planes, 2*hs[l_lo]-F+2, 2*ws[l_lo]-F+2]); a run that starts below ig.L takes that array as
+// d_a_in.
 static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, const ImgGeom &ig, int wavelet, double q,
-                       const double *d_mults, double *d_out) {
+                       const double *d_mults, double *d_out, int l_hi = -1, int l_lo = 1, const double *d_a_in = nullptr) {
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const int F = wv.F;
+    if (l_hi < 0) l_hi = ig.L;
+    const bool color = ctx->color_on && c == 3;
     if (ig.L == 0) {
         StageTimer t(ctx, ST_IDWT_REST);
         LAUNCHCHK(spiht_launch_dequant_plain(d_rec, d_out, (size_t)ig.enc_h * ig.enc_w, planes, c, d_mults, q, ctx->stream));
+        if (color)
+            LAUNCHCHK(spiht_launch_color3(d_out, d_out, planes / 3, (size_t)ig.enc_h * ig.enc_w, ctx->col_inv.A, ctx->col_inv.M,
+                                          ctx->col_inv.p, ctx->stream));
         return SPIHT_OK;
     }
     // intermediate approximations ping-pong between a0/a1; sizes 2*band-F+2
     size_t maxa = 0;
-    for (int l = ig.L; l >= 2; l--) maxa = std::max(maxa, (size_t)(2 * ig.hs[l] - F + 2) * (size_t)(2 * ig.ws[l] - F + 2));
+    for (int l = l_hi; l > l_lo; l--) maxa = std::max(maxa, (size_t)(2 * ig.hs[l] - F + 2) * (size_t)(2 * ig.ws[l] - F + 2));
     if (maxa) {
         CHK(ensure(ctx, ctx->a0, maxa * planes * 8));
         CHK(ensure(ctx, ctx->a1, maxa * planes * 8));
     }
-    const double *a_in = nullptr;
+    const double *a_in = d_a_in;
     int64_t ah = ig.ll_h, aw = ig.ll_w;
-    for (int l = ig.L; l >= 1; l--) {
+    if (l_hi < ig.L) { ah = 2 * ig.hs[l_hi + 1] - F + 2; aw = 2 * ig.ws[l_hi + 1] - F + 2; }
+    for (int l = l_hi; l >= l_lo; l--) {
         IdwtKArgs a;
         memset(&a, 0, sizeof(a));
         a.c = c;
@@ -991,9 +1023,10 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         a.first = (l == ig.L) ? 1 : 0;
         a.a_in = a_in;
         a.rec = d_rec;
-        a.out = (l == 1) ? d_out : (double *)((l & 1) ? ctx->a1.p : ctx->a0.p);
+        a.out = (l == l_lo) ? d_out : (double *)((l & 1) ? ctx->a1.p : ctx->a0.p);
         a.mults = d_mults;
         a.q = q;
+        if (color && l == 1) { a.color = 1; a.col = ctx->col_inv; }
         memcpy(a.lo, wv.rec_lo, sizeof(double) * F);
         memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
         {
@@ -1064,6 +1097,63 @@ extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec
         CHK(dwt_inverse(ctx, d_rec + (size_t)b0 * c * ig.enc_h * ig.enc_w, nb * (int)c, (int)c, ig, wavelet, q_scale,
                         d_mults, d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
     }
+    return SPIHT_OK;
+}
+
+// The inverse transform in two parts, so that a pipelined caller can queue the coarse levels (a quarter of the bytes,
+// six small launches at 1080p) where no list decoder shares the GPU and only level 1 beside it (OverlappedCodec):
+//   coarse: levels level..2 -> d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] (float64), the approximation level 1 starts from
+//   level1: d_rec + d_approx -> pixels.  With fewer than two levels the coarse part does nothing and d_approx is not read.
+static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int64_t B, int64_t c, int64_t H, int64_t W,
+                     int wavelet, int mode, int level, double q_scale, const double *channel_mults, double *d_img_out) {
+    if (!ctx || !d_rec || (!d_approx && !d_img_out)) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
+    if (B == 0) return SPIHT_OK;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    const bool coarse = d_img_out == nullptr;
+    if (coarse && ig.L < 2) return SPIHT_OK;
+    if (!coarse && ig.L >= 2 && !d_approx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const double *d_mults;
+    CHK(upload_mults(ctx, channel_mults, c, &d_mults));
+    const int F = SPIHT_WAVELETS[wavelet].F;
+    const size_t a_plane = ig.L >= 2 ? (size_t)(2 * ig.hs[2] - F + 2) * (size_t)(2 * ig.ws[2] - F + 2) : 0;
+    const int chunk = (int)std::max<int64_t>(1, 65535 / c);
+    for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = (int)std::min<int64_t>(chunk, B - b0);
+        const int32_t *rec = d_rec + (size_t)b0 * c * ig.enc_h * ig.enc_w;
+        double *ap = d_approx ? d_approx + (size_t)b0 * c * a_plane : nullptr;
+        if (coarse)
+            CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults, ap, ig.L, 2, nullptr));
+        else
+            CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
+                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, std::min(ig.L, 1), 1, ig.L >= 2 ? ap : nullptr));
+    }
+    return SPIHT_OK;
+}
+extern "C" int spiht_idwt_coarse_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H, int64_t W,
+                                           int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                                           double *d_approx) {
+    if (!d_approx) return SPIHT_ERR_ARG;
+    return idwt_part(ctx, d_rec, d_approx, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, nullptr);
+}
+extern "C" int spiht_idwt_level1_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const double *d_approx, int64_t B, int64_t c,
+                                           int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                           const double *channel_mults, double *d_img_out) {
+    if (!d_img_out) return SPIHT_ERR_ARG;
+    return idwt_part(ctx, d_rec, const_cast<double *>(d_approx), B, c, H, W, wavelet, mode, level, q_scale, channel_mults,
+                     d_img_out);
+}
+
+extern "C" int spiht_idwt_approx_shape(int64_t H, int64_t W, int wavelet, int level, int64_t *a_h, int64_t *a_w) {
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || !a_h || !a_w) return SPIHT_ERR_ARG;
+    ImgGeom ig;
+    const int F = SPIHT_WAVELETS[wavelet].F;
+    CHK(img_geometry(H, W, F, level, &ig));
+    *a_h = ig.L >= 2 ? 2 * ig.hs[2] - F + 2 : 0;
+    *a_w = ig.L >= 2 ? 2 * ig.ws[2] - F + 2 : 0;
     return SPIHT_OK;
 }
 
@@ -1393,6 +1483,26 @@ extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, i
     } else {
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * (size_t)(c * h * w) * 4, ctx->stream));
     }
+    return SPIHT_OK;
+}
+
+// Colour model of the coded picture, fused into the transform: while set, every image-level entry point of
+// this context takes and returns pixels in the caller's colour model (RGB) and codes them in the other one -- level 1 of the
+// forward transform converts on its loads (w = M_f * spow(A_f * u, p_f) per pixel), level 1 of the inverse transform on its
+// stores (A_i, M_i, p_i: the way back) -- for 3-channel float64 images.  A_f == NULL clears it.  Row-major 3x3 host arrays.
+extern "C" int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const double *M_f, double p_f, const double *A_i,
+                                    const double *M_i, double p_i) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!A_f) { ctx->color_on = false; return SPIHT_OK; }
+    if (!M_f || !A_i || !M_i) return SPIHT_ERR_ARG;
+    for (int i = 0; i < 9; i++) {
+        ctx->col_fwd.A[i] = A_f[i]; ctx->col_fwd.M[i] = M_f[i];
+        ctx->col_inv.A[i] = A_i[i]; ctx->col_inv.M[i] = M_i[i];
+    }
+    ctx->col_fwd.p = p_f;
+    ctx->col_inv.p = p_i;
+    ctx->color_on = true;
     return SPIHT_OK;
 }
 

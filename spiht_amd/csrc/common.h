@@ -126,6 +126,12 @@ struct PyrArgs {
     uint32_t *maxabs;
 };
 
+// Colour model change fused into level 1 of the transform (dwt.hip): per pixel w = M * spow(A * u, p), spow(x, p) =
+// sign(x)|x|^p -- the shape of RGB <-> IPT (spiht/color_models.py:6-13 -> colour-science; here the published matrices)
+struct Color3 {
+    double A[9], M[9], p;
+};
+
 // One forward DWT level (dwt.hip)
 struct DwtKArgs {
     int32_t c;             // channels (plane index = b*c + k)
@@ -137,8 +143,6 @@ struct DwtKArgs {
     int32_t f32;           // single-precision level (k_dwt_level_f32): `in` / `ll_out` then point to float arrays
     int32_t ov_h, ov_w;    // first output row / column that hangs over the bottom / right end of the input far enough for
                            // PyWavelets' overhang order to differ from ascending order; out_h / out_w: none (launcher)
-    int32_t et_x, et_y;    // first tile column / row holding such outputs: the tiles left of / above them run the kernel
-                           // instantiation without the overhang code, the others the one with it (launcher)
     const double *in;      // [planes, in_h, in_w]
     double *ll_out;        // [planes, out_h, out_w]
     int32_t *coeffs;       // [planes, enc_h, enc_w]
@@ -146,6 +150,8 @@ struct DwtKArgs {
     uint32_t *maxabs;      // device [B] or null: atomicMax of |quantised coefficient| per image
     double q;
     double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // dec_lo, dec_hi
+    int32_t color, pad2;   // level 1 of a 3-channel image with the colour model change on its loads (k_dwt1_color)
+    Color3 col;
 };
 
 // One inverse DWT level (dwt.hip)
@@ -164,4 +170,6 @@ struct IdwtKArgs {
     const double *mults;
     double q;
     double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // rec_lo, rec_hi
+    int32_t color, pad2;       // level 1 of a 3-channel image with the colour model change on its stores (k_idwt1_color)
+    Color3 col;
 };

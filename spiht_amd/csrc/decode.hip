@@ -111,6 +111,10 @@ struct DecShared {
             // there; zero where the stream bit is 0 (an entry cannot fire there), so the window's bits are the
             // ballot of "non-zero" and the sequencer reads nothing else
             uint8_t plav[DEC_PREP][64];
+            // helper -> workers: the bits of each window and of the one after it (zero at and past the end of the
+            // stream), so that a worker's window costs it no stream load.  A worker can lag DEC_RING windows behind the
+            // sequencer, the helper run DEC_PREP ahead of it.
+            uint64_t wbits[DEC_PREP + DEC_RING][2];
         };
     };
     uint64_t wpart[DEC_NW];     // per-wave partials of the block scans
@@ -358,8 +362,9 @@ __device__ __forceinline__ Item slot_unpack(DecShared &sh, const BitSrc &bs, uin
     it.first = k == seq0;
     it.b_lsp = sh.ph.b_lsp; it.b_lip = sh.ph.b_lip; it.b_ret = sh.ph.b_ret;
     it.Wb = widx << 6;
-    it.lo = stream_word64(bs, widx);
-    it.hi = stream_word64(bs, widx + 1);
+    const uint64_t *wb = sh.wbits[(k - seq0) % (DEC_PREP + DEC_RING)];  // written by the helper before the sequencer used it
+    it.lo = wb[0];
+    it.hi = wb[1];
     return it;
 }
 
@@ -492,11 +497,14 @@ template <bool META>
 __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const Item &it, const uint32_t *lip,
                                          uint32_t *lipn, uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits,
                                          int n, int32_t base_val, uint32_t lane, const Trace &tr) {
+    // the window's LIP entries first (it holds at most 64 tokens; it.m_rem of the list are left from e_start on)
+    const uint32_t pre = lip[it.e_start + (lane < it.m_rem ? lane : it.m_rem - 1u)];
     const LipWin lw = lip_window(it.lo, it.Wb, it.pos0, it.cin, it.m_rem, nbits);
     const bool isS = (lw.S_in >> lane) & 1ull;
     const uint32_t rank = mbcnt(lw.S_in);
     const bool sig = (lw.sig >> lane) & 1ull;
-    const uint32_t e = isS ? lip[it.e_start + rank] : 0u;
+    const uint32_t epick = (uint32_t)__shfl((int)pre, (int)rank);
+    const uint32_t e = isS ? epick : 0u;
     if (META) {
         if (isS) {
             tr_put(tr, it.Wb + lane, 0, n, e);              // action 0 (:707)
@@ -522,9 +530,12 @@ __device__ __forceinline__ void work_lip(DecShared &sh, const DecArgs &a, const 
 }
 
 // ---- per-lane work of one LIS window (worker); lane = stream position inside the window ----
+// `pre`: queue entry it.e_start + lane, loaded by the caller before anything else of the window was looked at (a window
+// of 64 bits holds at most 64 entries): the entry a lane needs is then a cross-lane read away instead of a second trip
+// to memory behind the stream bits.
 template <bool META>
 __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const Geom &g, const Item &it, uint32_t seqno,
-                                         const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
+                                         uint32_t pre, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
                                          uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
                                          int32_t base_val, uint32_t lane, const Trace &tr) {
     const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
@@ -548,7 +559,8 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
     const bool isE = ((own >> lane) & 1ull) && !payload;
     const uint64_t ES = __ballot(isE);
     const uint32_t mypos = it.Wb + lane;
-    const uint32_t e = isE ? cur[it.e_start + mbcnt(ES)] : 0u;
+    const uint32_t epick = (uint32_t)__shfl((int)pre, (int)mbcnt(ES));
+    const uint32_t e = isE ? epick : 0u;
     const uint32_t idx = e & IDXM;
     const bool isA = (e & ENT_A) != 0;
     const bool leaf = (e & ENT_LEAF) != 0;
@@ -676,8 +688,8 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
 template <bool META>
 __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, const Geom &g, uint32_t &myk, uint32_t par,
                                              const uint32_t *lip_rd, uint32_t *lip_wr, uint32_t *lip_app,
-                                             const uint32_t *cur, uint32_t *nxt, uint32_t *ret, uint32_t *lsp_idx,
-                                             int32_t *lsp_val, uint32_t nbits, int n,
+                                             const uint32_t *cur, uint32_t cur_len, uint32_t *nxt, uint32_t *ret,
+                                             uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
                                              int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr,
                                              const BitSrc &bs) {
     for (;;) {
@@ -697,8 +709,11 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
         }
         if (!got) break;
+        // the window's queue entries first (the only trip to memory of the window), then its bits from LDS
+        const uint32_t e0 = sh.ring[myk % DEC_RING].e_start + lane;
+        const uint32_t pre = cur[e0 < cur_len ? e0 : cur_len - 1u];
         const Item it = slot_unpack(sh, bs, myk);
-        work_lis<META>(sh, a, g, it, myk, cur, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
+        work_lis<META>(sh, a, g, it, myk, pre, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
         myk += DEC_NWK;
@@ -737,6 +752,7 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
             }
             const uint32_t slot = (j + u) % DEC_PREP;
             sh.plav[slot][lane] = (uint8_t)((bb & 1u) ? 5 + ns : 0);  // non-zero <=> the stream bit is 1
+            if (lane < 2) sh.wbits[(j + u) % (DEC_PREP + DEC_RING)][lane] = lane ? hi : lo;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
@@ -1166,7 +1182,7 @@ void k_decode(DecArgs a) {
                 } else if (wave == 1) {
                     helper_phase(sh, bs, par, P >> 6, lane);
                 } else if (DEC_IS_WORKER(wave)) {
-                    worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, nxt, ret, lsp_idx, lsp_val, nbits,
+                    worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, cur_len, nxt, ret, lsp_idx, lsp_val, nbits,
                                        n, base_val, DEC_WK(wave), lane, tr, bs);
                 }
                 PF_ADD(2);

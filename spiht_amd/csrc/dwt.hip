@@ -36,14 +36,19 @@
 // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Remap the linear block id so
 // that each XCD walks one contiguous range of tiles: neighbouring tiles (shared halo columns/rows on the read
 // side, shared partial cache lines on the write side) then meet in the same L2.  Speed only, never correctness.
-__device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t &bx, uint32_t &by, uint32_t &bz) {
-    const uint32_t nt = gx * gy * gz, L = blockIdx.x;
+__device__ __forceinline__ void xcd_tile_at(uint32_t L, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t &bx, uint32_t &by,
+                                            uint32_t &bz) {
+    const uint32_t nt = gx * gy * gz;
     const uint32_t q = nt >> 3, r = nt & 7u, x = L & 7u, j = L >> 3;
     const uint32_t T = x * q + (x < r ? x : r) + j;
     bx = T % gx;
     const uint32_t t2 = T / gx;
     by = t2 % gy;
     bz = t2 / gy;
+}
+
+__device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, uint32_t &bx, uint32_t &by, uint32_t &bz) {
+    xcd_tile_at(blockIdx.x, gx, gy, gz, bx, by, bz);
 }
 
 __device__ __forceinline__ int ext_index(int i, int N, int mode) {
@@ -79,34 +84,15 @@ __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes).  LOM / HIM: bit j set = tap j of dec_lo / dec_hi is non-zero;
 // a zero tap contributes exactly nothing (0*x added to the running sum), so skipping it changes no bit and
 // removes a third (bior2.2) to a fifth of the float64 arithmetic.
-// EDGE: the instantiation for the tiles that hold the bottom / right overhang outputs, which are summed in PyWavelets'
-// order (below); the interior tiles run the instantiation without that code (it costs the fast path 10 % when it is
-// merely present: measured).  The two launches cover the tile grid between them (DwtKArgs::et_*).
-template <int F, uint32_t LOM, uint32_t HIM, bool EDGE>
-__global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
+// One tile of k_dwt_level.
+template <int F, uint32_t LOM, uint32_t HIM, int PS, int NR>
+__device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS], double (&s_hi)[2][PS], int (&s_row)[NR],
+                                         uint32_t tbx, uint32_t tby, uint32_t tbz) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
-    constexpr int NR = 2 * DW_TH + F - 2;  // input rows needed
     constexpr int HC = (NC + 1) / 2;       // columns per parity plane
     static_assert(NC <= DW_BLOCK, "one thread per input column");
-    // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
-    // lanes of one ds_write_b64 lane group land on different banks
-    constexpr int RS = HC + 1, PS = DW_TH * RS + (24 - (DW_TH * RS) % 16) % 16;  // PS % 16 == 8
-    __shared__ double s_lo[2][PS];
-    __shared__ double s_hi[2][PS];
-    __shared__ int s_row[NR];
-    uint32_t tbx, tby, tbz;
-    if (!EDGE) {
-        xcd_tile((uint32_t)a.et_x, (uint32_t)a.et_y, a.planes, tbx, tby, tbz);  // tiles left of et_x and above et_y
-    } else {
-        // the other tiles of a plane, numbered: the column strip right of et_x (all tile rows), then the rest of the
-        // bottom strip
-        const uint32_t gx = (a.out_w + DW_TW - 1) / DW_TW, gy = (a.out_h + DW_TH - 1) / DW_TH;
-        const uint32_t sw = gx - (uint32_t)a.et_x, ns = sw * gy, ne = ns + (uint32_t)a.et_x * (gy - (uint32_t)a.et_y);
-        uint32_t e, dummy;
-        xcd_tile(ne, 1, a.planes, e, dummy, tbz);
-        if (e < ns) { tbx = (uint32_t)a.et_x + e % sw; tby = e / sw; }
-        else { e -= ns; tbx = e % (uint32_t)a.et_x; tby = (uint32_t)a.et_y + e / (uint32_t)a.et_x; }
-    }
+    static_assert(NR == 2 * DW_TH + F - 2, "input rows needed");
+    constexpr int RS = HC + 1;
     const int plane = (int)tbz;
     const int oh0 = (int)tby * DW_TH, ow0 = (int)tbx * DW_TW;
     const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
@@ -139,26 +125,6 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
             s_lo[par][o * RS + hc] = sl;
             s_hi[par][o * RS + hc] = shh;
         }
-        // Bottom overhang, PyWavelets' order (downsampling_convolution): for an output that hangs over the end of the
-        // input (2o+1 >= N) the taps that read the signal extension come first, nearest first (tap 2o+1-N down to 0),
-        // then the others ascending.  Only the last row or two of a level differ in a bit from the ascending sums above
-        // (ov_h: set by the launcher), so only the bottom tile row comes here (a block-uniform branch); the samples are
-        // loaded again -- run-time tap order would turn x[] into scratch memory.
-        if (EDGE && oh0 + DW_TH > a.ov_h) {
-            for (int o = max(a.ov_h - oh0, 0); o < DW_TH && oh0 + o < a.out_h; o++) {
-                const int jb = 2 * (oh0 + o) + 1 - a.in_h;
-                double sl = 0.0, shh = 0.0;
-                for (int s2 = 0; s2 < F; s2++) {
-                    const int j = s2 <= jb ? jb - s2 : s2;
-                    const int gr = s_row[2 * o + F - 1 - j];
-                    const double v = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
-                    sl += a.lo[j] * v;
-                    shh += a.hi[j] * v;
-                }
-                s_lo[par][o * RS + hc] = sl;
-                s_hi[par][o * RS + hc] = shh;
-            }
-        }
     }
     __syncthreads();
 
@@ -184,33 +150,117 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
             if ((LOM >> j) & 1u) { aa += a.lo[j] * vl; da += a.lo[j] * vh; }
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }
-        if (EDGE && ow >= a.ov_w) {  // right overhang: the same order along this axis (the last column or two of a level)
-            const int jb = 2 * ow + 1 - a.in_w;
-            aa = 0.0; ad = 0.0; da = 0.0; dd = 0.0;
-            for (int s2 = 0; s2 < F; s2++) {
-                const int j = s2 <= jb ? jb - s2 : s2;
-                const double vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
-                const double vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
-                aa += a.lo[j] * vl; da += a.lo[j] * vh;
-                ad += a.hi[j] * vl; dd += a.hi[j] * vh;
-            }
-        }
         const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        // the few outputs of the bottom / right overhang whose sum depends on PyWavelets' tap order are computed again
+        // by k_dwt_edge, which overwrites them and accounts for their magnitude
+        const bool mine = oh < a.ov_h && ow < a.ov_w;
         if (a.last) {
             const int32_t qaa = quant(aa, mk, a.q, has_m);
             co[(size_t)oh * a.enc_w + ow] = qaa;
-            amax = max(amax, iabs_u(qaa));
+            if (mine) amax = max(amax, iabs_u(qaa));
         } else {
             llo[(size_t)oh * a.out_w + ow] = aa;
         }
         co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;                 // 'ad' top-right
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;               // 'da' bottom-left
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
-        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+        if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
         for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
         if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+
+template <int F, uint32_t LOM, uint32_t HIM>
+__global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
+    constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
+    // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
+    // lanes of one ds_write_b64 lane group land on different banks
+    constexpr int RS = HC + 1, PS = DW_TH * RS + (24 - (DW_TH * RS) % 16) % 16;  // PS % 16 == 8
+    __shared__ double s_lo[2][PS];
+    __shared__ double s_hi[2][PS];
+    __shared__ int s_row[NR];
+    uint32_t tbx, tby, tbz;
+    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+    dwt_tile<F, LOM, HIM, PS, NR>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
+}
+
+// ---- the bottom / right overhang of a float64 level, in PyWavelets' summation order -----------------------------
+// pywt's downsampling_convolution adds the taps in ascending order -- except for the outputs that hang over the end
+// of the input (jb = 2o+1-N >= 0, the last F/2 or so output rows and columns of a level): there the taps that read the
+// signal extension come first, nearest first (tap jb down to 0), then the others ascending.  The sums differ in the
+// last bits, and on 8-bit pictures with flat areas (coefficient x q exactly an integer) the truncating quantiser turns
+// that into +-1 (tests/golden/blocky_pywt.npz).  k_dwt_level keeps its compile-time ascending order everywhere (the
+// overhang code inside it -- as a block-uniform branch, a second instantiation for the edge tiles, one launch or two,
+// a side stream -- cost the level 5 to 12 %: measured); this kernel then recomputes just the outputs whose order
+// matters (ov_h / ov_w: the last row and column of a bior level), one thread each, straight from global memory, and
+// overwrites them.  grid: (ceil(outputs / 256), planes).
+template <int F>
+__global__ __launch_bounds__(256) void k_dwt_edge(DwtKArgs a) {
+    __shared__ double s_f[2][F];  // taps, indexed at run time below
+    if (threadIdx.x < F) { s_f[0][threadIdx.x] = a.lo[threadIdx.x]; s_f[1][threadIdx.x] = a.hi[threadIdx.x]; }
+    __syncthreads();
+    const int nr = a.out_h - a.ov_h, nc = a.out_w - a.ov_w;        // overhang rows / columns
+    const int nA = nr * a.out_w, total = nA + a.ov_h * nc;          // all columns of those rows + the rest of those columns
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int plane = blockIdx.y;
+    uint32_t amax = 0;
+    if (t < total) {
+        int oh, ow;
+        if (t < nA) { oh = a.ov_h + t / a.out_w; ow = t % a.out_w; }
+        else { const int u = t - nA; oh = u / nc; ow = a.ov_w + u % nc; }
+        const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
+        const int ir = 2 * oh + 1, ic = 2 * ow + 1;
+        const int jbr = oh >= a.ov_h ? ir - a.in_h : -1, jbc = ow >= a.ov_w ? ic - a.in_w : -1;
+        int gr[F];
+#pragma unroll
+        for (int r = 0; r < F; r++) gr[r] = ext_index(ir - r, a.in_h, a.mode);
+        // Column by column in the order axis -1 asks for; per column the F samples are loaded first (independent loads),
+        // then added in the order the row asks for -- a sample is picked by comparing indices, registers cannot be
+        // indexed at run time.  (One load at a time, as a plain double loop does it, this kernel took 0.26 ms at
+        // 256 x 1080p, 7 % of the level.)
+        double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
+#pragma unroll F <= 6 ? F : 1
+        for (int s1 = 0; s1 < F; s1++) {
+            const int j = s1 <= jbc ? jbc - s1 : s1;
+            const int gc = ext_index(ic - j, a.in_w, a.mode);
+            double xv[F];
+#pragma unroll
+            for (int r = 0; r < F; r++) xv[r] = (gc < 0 || gr[r] < 0) ? 0.0 : in[(size_t)gr[r] * a.in_w + gc];
+            double tl = 0.0, th = 0.0;
+#pragma unroll
+            for (int s2 = 0; s2 < F; s2++) {
+                const int j2 = s2 <= jbr ? jbr - s2 : s2;
+                double v = xv[0];
+#pragma unroll
+                for (int r = 1; r < F; r++) v = (j2 == r) ? xv[r] : v;
+                tl += s_f[0][j2] * v;
+                th += s_f[1][j2] * v;
+            }
+            aa += s_f[0][j] * tl; da += s_f[0][j] * th;
+            ad += s_f[1][j] * tl; dd += s_f[1][j] * th;
+        }
+        const int k = plane % a.c;
+        const bool has_m = a.mults != nullptr;
+        const double mk = has_m ? a.mults[k] : 1.0;
+        int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+        const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        if (a.last) {
+            const int32_t qaa = quant(aa, mk, a.q, has_m);
+            co[(size_t)oh * a.enc_w + ow] = qaa;
+            amax = iabs_u(qaa);
+        } else {
+            a.ll_out[(size_t)plane * a.out_h * a.out_w + (size_t)oh * a.out_w + ow] = aa;
+        }
+        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
+        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
+        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
+        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((threadIdx.x & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
     }
 }
 
@@ -446,6 +496,209 @@ __global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint
 }
 #endif  // SPIHT_DIAG
 
+// ---- colour ---------------------------------------------------------------------------------------------------------
+// One pixel of the colour model change.  Shared by the stand-alone kernel (k_color3) and the fused level-1 kernels, and
+// this file is compiled without multiply-add contraction: the three produce the same bits.  numpy's dot order.
+__device__ __forceinline__ void color3_px(const Color3 &c, double u0, double u1, double u2, double &w0, double &w1, double &w2) {
+    double v[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double x = (u0 * c.A[3 * r] + u1 * c.A[3 * r + 1]) + u2 * c.A[3 * r + 2];
+#ifdef SPIHT_COLOR_POW   // the device library's pow(): <= 1 ulp, about 250 float64 instruction slots per call
+        const double m = pow(fabs(x), c.p);
+#else                    // exp(p log|x|): a few ulp (|p ln x| + 1 units in the last place), a third of the cost -- the colour
+                         // model change is arithmetic-bound (three powers per pixel), and its parity is unpinned anyway
+        const double ax = fabs(x);
+        const double m = ax > 0.0 ? exp(c.p * log(ax)) : 0.0;
+#endif
+        v[r] = x < 0.0 ? -m : (x > 0.0 ? m : 0.0);
+    }
+    w0 = (v[0] * c.M[0] + v[1] * c.M[1]) + v[2] * c.M[2];
+    w1 = (v[0] * c.M[3] + v[1] * c.M[4]) + v[2] * c.M[5];
+    w2 = (v[0] * c.M[6] + v[1] * c.M[7]) + v[2] * c.M[8];
+}
+
+// Stand-alone colour model change of a batch of 3-channel float64 images [B,3,npix]; in place allowed.  The checker of
+// the fused kernels, and the path of images that have no transform level.
+__global__ __launch_bounds__(256) void k_color3(const double *__restrict__ in, double *__restrict__ out, size_t npix, Color3 c) {
+    const size_t img = (size_t)blockIdx.y * 3 * npix;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (size_t)gridDim.x * 256) {
+        double w0, w1, w2;
+        color3_px(c, in[img + t], in[img + npix + t], in[img + 2 * npix + t], w0, w1, w2);
+        out[img + t] = w0;
+        out[img + npix + t] = w1;
+        out[img + 2 * npix + t] = w2;
+    }
+}
+extern "C" int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M,
+                                   double p, hipStream_t st) {
+    Color3 c;
+    for (int i = 0; i < 9; i++) { c.A[i] = A[i]; c.M[i] = M[i]; }
+    c.p = p;
+    const unsigned gx = (unsigned)((npix + 1023) / 1024 < 1 ? 1 : (npix + 1023) / 1024);
+    hipLaunchKernelGGL(k_color3, dim3(gx, (unsigned)B), dim3(256), 0, st, d_in, d_out, npix, c);
+    return (int)hipGetLastError();
+}
+
+// ---- level 1 of a 3-channel image with the colour model change on its loads ---------------------
+// The change needs all three planes of a pixel and costs three pow() per pixel -- about as much arithmetic as the
+// transform costs memory time -- so every pixel must be converted exactly once: a workgroup owns a strip of C1_SW output
+// columns of ALL THREE channels and marches down C1_ROWS output rows.  Thread = input column: per step it loads the
+// R, G, B samples of two new rows (C1_PF steps ahead), converts them, slides them into a register window of F rows per
+// channel, and filters down the column; the low / high rows of the three channels go through a double-buffered LDS row
+// to the axis -1 filter (threads 0..127: aa, ad from the low rows; 128..255: da, dd from the high rows).  One barrier per
+// output row; a pixel is loaded and converted once per strip (F-2 rows of overlap between vertically adjacent strips).
+// Same sums in the same order as k_dwt_level on converted pixels, overhang order included: bit-identical outputs.
+#define C1_PF 2
+#define C1_ROWS 136
+template <int F, uint32_t LOM, uint32_t HIM>
+__global__ __launch_bounds__(256) void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {
+    constexpr int SW = (256 - (F - 2)) / 2;  // output columns per strip: exactly 256 input columns
+    constexpr int HC = 128 + 2;
+    __shared__ double s_lo[2][3][2][HC];     // [step parity][channel][column parity][column >> 1]
+    __shared__ double s_hi[2][3][2][HC];
+    uint32_t tbx, tby, tbz;
+    xcd_tile(gx, gy, a.planes / 3, tbx, tby, tbz);
+    const int img = (int)tbz;
+    const int ow0 = (int)tbx * SW, oa = (int)tby * C1_ROWS;
+    const int ob = min(oa + C1_ROWS, a.out_h);
+    const size_t npl = (size_t)a.in_h * a.in_w;
+    const double *__restrict__ in = a.in + (size_t)img * 3 * npl;
+    const int tid = threadIdx.x;
+    const int gc = ext_index(2 * ow0 + 2 - F + tid, a.in_w, a.mode);
+    auto ld = [&](int r, double &u0, double &u1, double &u2) {  // raw R, G, B of (row r, this column), extension applied
+        const int gr = ext_index(r, a.in_h, a.mode);
+        const bool z = gc < 0 || gr < 0;
+        const size_t o = z ? 0 : (size_t)gr * a.in_w + gc;
+        u0 = in[o]; u1 = in[o + npl]; u2 = in[o + 2 * npl];
+        if (z) { u0 = 0.0; u1 = 0.0; u2 = 0.0; }
+    };
+    // "zero" extension pads the CONVERTED signal with zeros (pywt extends what it is given): convert, then zero
+    auto cv = [&](int r, double u0, double u1, double u2, double &w0, double &w1, double &w2) {
+        color3_px(a.col, u0, u1, u2, w0, w1, w2);
+        if (gc < 0 || ext_index(r, a.in_h, a.mode) < 0) { w0 = 0.0; w1 = 0.0; w2 = 0.0; }
+    };
+    double win[3][F];  // rows 2o+2-F .. 2o+1 of output row o, converted
+#pragma unroll
+    for (int t = 0; t < F; t++) {
+        double u0, u1, u2;
+        ld(2 * oa + 2 - F + t, u0, u1, u2);
+        cv(2 * oa + 2 - F + t, u0, u1, u2, win[0][t], win[1][t], win[2][t]);
+    }
+    double pq[C1_PF][2][3];  // raw samples of the two rows each of the next C1_PF steps brings in
+#pragma unroll
+    for (int u = 0; u < C1_PF; u++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) ld(2 * (oa + 1 + u) + e, pq[u][e][0], pq[u][e][1], pq[u][e][2]);
+
+    const bool has_m = a.mults != nullptr;
+    double mk[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) mk[ch] = has_m ? a.mults[ch] : 1.0;
+    const int role = tid >> 7, wcol = tid & 127;
+    const int ow = ow0 + wcol;
+    const bool wr = wcol < SW && ow < a.out_w;
+    const size_t cpl = (size_t)a.enc_h * a.enc_w, lpl = (size_t)a.out_h * a.out_w;
+    int32_t *__restrict__ co = a.coeffs + (size_t)img * 3 * cpl;
+    double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)img * 3 * lpl;
+    uint32_t amax = 0;
+    const int par = tid & 1, hc = tid >> 1;
+
+    for (int o0 = oa; o0 < ob; o0 += C1_PF) {
+#pragma unroll
+        for (int u = 0; u < C1_PF; u++) {
+            const int o = o0 + u;
+            // ---- axis -2 for output row o, three channels ----
+            if (o < a.ov_h) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    double sl = 0.0, shh = 0.0;
+#pragma unroll
+                    for (int j = 0; j < F; j++) {
+                        if ((LOM >> j) & 1u) sl += a.lo[j] * win[ch][F - 1 - j];
+                        if ((HIM >> j) & 1u) shh += a.hi[j] * win[ch][F - 1 - j];
+                    }
+                    s_lo[u & 1][ch][par][hc] = sl;
+                    s_hi[u & 1][ch][par][hc] = shh;
+                }
+            } else {  // bottom overhang: PyWavelets' order (k_dwt_level); the window element is picked with selects
+                const int jb = 2 * o + 1 - a.in_h;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    double sl = 0.0, shh = 0.0;
+                    for (int s2 = 0; s2 < F; s2++) {
+                        const int j = s2 <= jb ? jb - s2 : s2;
+                        double v = win[ch][0];
+#pragma unroll
+                        for (int t = 1; t < F; t++) v = (F - 1 - j == t) ? win[ch][t] : v;
+                        sl += a.lo[j] * v;
+                        shh += a.hi[j] * v;
+                    }
+                    s_lo[u & 1][ch][par][hc] = sl;
+                    s_hi[u & 1][ch][par][hc] = shh;
+                }
+            }
+            // slide the windows: the two rows this step brings in are converted now, their successors requested
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+                for (int t = 0; t < F - 2; t++) win[ch][t] = win[ch][t + 2];
+#pragma unroll
+            for (int e = 0; e < 2; e++)
+                cv(2 * (o + 1) + e, pq[u][e][0], pq[u][e][1], pq[u][e][2], win[0][F - 2 + e], win[1][F - 2 + e], win[2][F - 2 + e]);
+#pragma unroll
+            for (int e = 0; e < 2; e++) ld(2 * (o + 1 + C1_PF) + e, pq[u][e][0], pq[u][e][1], pq[u][e][2]);
+            __syncthreads();
+            // ---- axis -1: two sub-bands per thread and channel ----
+            if (wr && o < ob) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const double(*src)[HC] = role ? s_hi[u & 1][ch] : s_lo[u & 1][ch];
+                    double r0 = 0.0, r1 = 0.0;  // role 0: aa, ad   role 1: da, dd
+                    if (ow < a.ov_w) {
+#pragma unroll
+                        for (int j = 0; j < F; j++) {
+                            const double v = src[(F - 1 - j) & 1][wcol + ((F - 1 - j) >> 1)];
+                            if ((LOM >> j) & 1u) r0 += a.lo[j] * v;
+                            if ((HIM >> j) & 1u) r1 += a.hi[j] * v;
+                        }
+                    } else {  // right overhang
+                        const int jb = 2 * ow + 1 - a.in_w;
+                        for (int s2 = 0; s2 < F; s2++) {
+                            const int j = s2 <= jb ? jb - s2 : s2;
+                            const double v = src[(F - 1 - j) & 1][wcol + ((F - 1 - j) >> 1)];
+                            r0 += a.lo[j] * v;
+                            r1 += a.hi[j] * v;
+                        }
+                    }
+                    int32_t *cc = co + (size_t)ch * cpl;
+                    const int32_t q1 = quant(r1, mk[ch], a.q, has_m);
+                    amax = max(amax, iabs_u(q1));
+                    if (role == 0) {
+                        if (a.last) {
+                            const int32_t q0 = quant(r0, mk[ch], a.q, has_m);
+                            cc[(size_t)o * a.enc_w + ow] = q0;
+                            amax = max(amax, iabs_u(q0));
+                        } else {
+                            llo[(size_t)ch * lpl + (size_t)o * a.out_w + ow] = r0;
+                        }
+                        cc[(size_t)o * a.enc_w + a.off_w + ow] = q1;                      // 'ad' top-right
+                    } else {
+                        const int32_t q0 = quant(r0, mk[ch], a.q, has_m);
+                        amax = max(amax, iabs_u(q0));
+                        cc[(size_t)(a.off_h + o) * a.enc_w + ow] = q0;                     // 'da' bottom-left
+                        cc[(size_t)(a.off_h + o) * a.enc_w + a.off_w + ow] = q1;           // 'dd' bottom-right
+                    }
+                }
+            }
+        }
+    }
+    if (a.maxabs != nullptr) {
+        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
+        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[img], amax);
+    }
+}
+
 // zero the padding cells of coeffs_to_array: per level the strip below 'ad' and the strip right of 'da'.
 // grid: (blocks, nrects, planes)
 struct PadRects {
@@ -618,6 +871,123 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
     }
 }
 
+// ---- level 1 of the inverse transform of a 3-channel image with the colour model change on its stores ------------
+// k_idwt_level for the three channels of a tile at once (same staging, same sums in the same order), so that the three
+// values of an output pixel meet in one thread, which converts them (color3_px: three pow() per pixel) and stores the
+// result: the transformed picture in the coded colour model never exists in memory.  Arithmetic-bound, so the tile is
+// smaller than k_idwt_level's (IWC_TH rows: 38.6 KB of LDS for the three channels, four workgroups per CU).
+#define IWC_TH 8
+template <int F, uint32_t LOM, uint32_t HIM>
+__global__ __launch_bounds__(DW_BLOCK) void k_idwt1_color(IdwtKArgs a) {
+    constexpr int HF = F / 2;
+    constexpr int KH = IWC_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IWC_TH / 4 + HF - 1;
+    __shared__ double s_b[3][4][KH][KW + 1];  // per channel: aa, ad, da, dd (dequantised)
+    uint32_t tbx, tby, tbz;
+    xcd_tile((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IWC_TH - 1) / IWC_TH, a.planes / 3, tbx, tby, tbz);
+    const int img = (int)tbz;
+    const int m0 = (int)tby * IWC_TH, n0 = (int)tbx * IW_TW;
+    const int kh0 = m0 / 2, kw0 = n0 / 2;
+    const bool has_m = a.mults != nullptr;
+    const int tid = threadIdx.x;
+    const size_t cpl = (size_t)a.enc_h * a.enc_w, apl = (size_t)a.a_h * a.a_w, opl = (size_t)a.out_h * a.out_w;
+
+    for (int p = tid; p < 3 * KH * KW; p += DW_BLOCK) {
+        const int ch = p / (KH * KW), q = p - ch * (KH * KW);
+        const int r = q / KW, cidx = q - r * KW;
+        const int bi = kh0 + r, bj = kw0 + cidx;
+        const double mk = has_m ? a.mults[ch] : 1.0;
+        const bool zero_ok = (!has_m || mk > 0.0) && a.q > 0.0;  // 0/m/q == +0.0 exactly: skip the divisions
+        const int32_t *__restrict__ rec = a.rec + ((size_t)img * 3 + ch) * cpl;
+        double vaa = 0.0, vad = 0.0, vda = 0.0, vdd = 0.0;
+        if (bi < a.band_h && bj < a.band_w) {
+            const int32_t rad = rec[(size_t)bi * a.enc_w + a.off_w + bj];
+            const int32_t rda = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
+            const int32_t rdd = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            if (a.first) {
+                const int32_t raa = rec[(size_t)bi * a.enc_w + bj];
+                vaa = (raa == 0 && zero_ok) ? 0.0 : dequant(raa, mk, a.q, has_m);
+            } else {
+                vaa = a.a_in[((size_t)img * 3 + ch) * apl + (size_t)bi * a.a_w + bj];
+            }
+            vad = (rad == 0 && zero_ok) ? 0.0 : dequant(rad, mk, a.q, has_m);
+            vda = (rda == 0 && zero_ok) ? 0.0 : dequant(rda, mk, a.q, has_m);
+            vdd = (rdd == 0 && zero_ok) ? 0.0 : dequant(rdd, mk, a.q, has_m);
+        }
+        s_b[ch][0][r][cidx] = vaa; s_b[ch][1][r][cidx] = vad; s_b[ch][2][r][cidx] = vda; s_b[ch][3][r][cidx] = vdd;
+    }
+    __syncthreads();
+
+    const int nn = tid & (IW_TW - 1), half = tid / IW_TW;
+    const int n = n0 + nn, np = n & 1, cl = nn / 2;
+    double tlo[HF], thi[HF];
+#pragma unroll
+    for (int s = 0; s < HF; s++) {
+        tlo[s] = a.lo[np + F - 2 - 2 * s];
+        thi[s] = a.hi[np + F - 2 - 2 * s];
+    }
+    double wl[3][HF], wh[3][HF];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+        for (int s = 0; s < HF; s++) { wl[ch][s] = 0.0; wh[ch][s] = 0.0; }
+    double *__restrict__ out = a.out + (size_t)img * 3 * opl;
+    const int rbase = half * (IWC_TH / 4);
+#pragma unroll
+    for (int rr = 0; rr < KHH; rr++) {
+        const int r = rbase + rr;
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {  // axis -1 synthesis of band row r at output column n (order: k_idwt_level)
+            double ta = 0.0, td = 0.0, ua = 0.0, ud = 0.0;
+#pragma unroll
+            for (int j = 0; j < HF; j++) {
+                const int s = HF - 1 - j;
+                constexpr uint32_t PAIR = 3u;
+                const bool lnz = ((LOM >> (F - 2 - 2 * s)) & PAIR) != 0, hnz = ((HIM >> (F - 2 - 2 * s)) & PAIR) != 0;
+                if (lnz) {
+                    ta += s_b[ch][0][r][cl + s] * tlo[s];
+                    ua += s_b[ch][2][r][cl + s] * tlo[s];
+                }
+                if (hnz) {
+                    td += s_b[ch][1][r][cl + s] * thi[s];
+                    ud += s_b[ch][3][r][cl + s] * thi[s];
+                }
+            }
+            const double tl = (0.0 + ta) + td, th = (0.0 + ua) + ud;
+#pragma unroll
+            for (int s = 0; s < HF - 1; s++) { wl[ch][s] = wl[ch][s + 1]; wh[ch][s] = wh[ch][s + 1]; }
+            wl[ch][HF - 1] = tl;
+            wh[ch][HF - 1] = th;
+        }
+        if (rr >= HF - 1) {
+            const int m = 2 * (kh0 + r - (HF - 1));
+#pragma unroll
+            for (int mp = 0; mp < 2; mp++) {
+                double px[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    double sa = 0.0, sd = 0.0;
+#pragma unroll
+                    for (int j = 0; j < HF; j++) {
+                        const int s = HF - 1 - j;
+                        const bool lnz = (LOM >> (mp + F - 2 - 2 * s)) & 1u, hnz = (HIM >> (mp + F - 2 - 2 * s)) & 1u;
+                        if (lnz) sa += wl[ch][s] * a.lo[mp + F - 2 - 2 * s];
+                        if (hnz) sd += wh[ch][s] * a.hi[mp + F - 2 - 2 * s];
+                    }
+                    px[ch] = (0.0 + sa) + sd;
+                }
+                if (m + mp < a.out_h && n < a.out_w) {
+                    double w0, w1, w2;
+                    color3_px(a.col, px[0], px[1], px[2], w0, w1, w2);
+                    const size_t o = (size_t)(m + mp) * a.out_w + n;
+                    out[o] = w0;
+                    out[o + opl] = w1;
+                    out[o + 2 * opl] = w2;
+                }
+            }
+        }
+    }
+}
+
 // ---- host launchers -----------------------------------------------------------------------------
 
 template <int F, uint32_t LOM, uint32_t HIM>
@@ -628,6 +998,16 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     if (a.f32) {
         uint32_t ntf = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW32_TH - 1) / DW32_TH) * (uint32_t)planes;
         hipLaunchKernelGGL((k_dwt_level_f32<F, LOM, HIM>), dim3(ntf), dim3(DW_BLOCK), 0, st, a);
+        return (int)hipGetLastError();
+    }
+    if (a.color) {  // level 1 of a 3-channel image, colour model change on the loads
+        constexpr int SW = (256 - (F - 2)) / 2;
+        int z = 0;
+        while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
+        if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
+        if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
+        const uint32_t gx = (uint32_t)((a.out_w + SW - 1) / SW), gy = (uint32_t)((a.out_h + C1_ROWS - 1) / C1_ROWS);
+        hipLaunchKernelGGL((k_dwt1_color<F, LOM, HIM>), dim3(gx * gy * (uint32_t)(planes / 3)), dim3(256), 0, st, a, gx, gy);
         return (int)hipGetLastError();
     }
 #ifdef SPIHT_DIAG
@@ -647,14 +1027,10 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
     if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
-    const int gx = (a.out_w + DW_TW - 1) / DW_TW, gy = (a.out_h + DW_TH - 1) / DW_TH;
-    a.et_x = min(gx, a.ov_w / DW_TW);  // first tile column / row that holds such outputs (gx / gy: none)
-    a.et_y = min(gy, a.ov_h / DW_TH);
-    if (a.ov_w >= a.out_w) a.et_x = gx;
-    if (a.ov_h >= a.out_h) a.et_y = gy;
-    const uint32_t n_in = (uint32_t)a.et_x * (uint32_t)a.et_y, n_edge = (uint32_t)gx * (uint32_t)gy - n_in;
-    if (n_in) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(n_in * (uint32_t)planes), dim3(DW_BLOCK), 0, st, a);
-    if (n_edge) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(n_edge * (uint32_t)planes), dim3(DW_BLOCK), 0, st, a);
+    const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
+    if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 // specialised for the zero-tap pattern of the known filter bank of that length, generic otherwise
@@ -671,6 +1047,11 @@ static int launch_dwt_F(const DwtKArgs &a, int planes, hipStream_t st) {
 template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
+    if (a.color) {  // level 1 of a 3-channel image, colour model change on the stores
+        uint32_t ntc = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW) * (uint32_t)((a.out_h + IWC_TH - 1) / IWC_TH) * (uint32_t)(planes / 3);
+        hipLaunchKernelGGL((k_idwt1_color<F, LOM, HIM>), dim3(ntc), dim3(DW_BLOCK), 0, st, a);
+        return (int)hipGetLastError();
+    }
     uint32_t nt = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW) * (uint32_t)((a.out_h + IW_TH - 1) / IW_TH) * (uint32_t)planes;
     hipLaunchKernelGGL((k_idwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();

@@ -288,39 +288,6 @@ extern "C" int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint
     return (int)hipGetLastError();
 }
 
-// Colour model change of a batch of 3-channel float64 images, per pixel: v = A*u, v = sign(v)|v|^p, w = M*v -- the
-// shape of the RGB <-> IPT transform (reference: spiht/color_models.py:6-13 -> colour-science; here the published
-// Ebner-Fairchild matrices, passed in by the host so that host and device use the same numbers).  In place allowed.
-struct Color3Args {
-    double A[9], M[9], p;
-};
-__global__ __launch_bounds__(256) void k_color3(const double *__restrict__ in, double *__restrict__ out, size_t npix,
-                                                Color3Args c) {
-    const size_t img = (size_t)blockIdx.y * 3 * npix;
-    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (size_t)gridDim.x * 256) {
-        const double u0 = in[img + t], u1 = in[img + npix + t], u2 = in[img + 2 * npix + t];
-        double v[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const double x = (u0 * c.A[3 * r] + u1 * c.A[3 * r + 1]) + u2 * c.A[3 * r + 2];  // numpy's dot order
-            const double m = pow(fabs(x), c.p);
-            v[r] = x < 0.0 ? -m : (x > 0.0 ? m : 0.0);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; r++)
-            out[img + (size_t)r * npix + t] = (v[0] * c.M[3 * r] + v[1] * c.M[3 * r + 1]) + v[2] * c.M[3 * r + 2];
-    }
-}
-extern "C" int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M,
-                                   double p, hipStream_t st) {
-    Color3Args c;
-    for (int i = 0; i < 9; i++) { c.A[i] = A[i]; c.M[i] = M[i]; }
-    c.p = p;
-    const unsigned gx = (unsigned)((npix + 1023) / 1024 < 1 ? 1 : (npix + 1023) / 1024);
-    hipLaunchKernelGGL(k_color3, dim3(gx, (unsigned)B), dim3(256), 0, st, d_in, d_out, npix, c);
-    return (int)hipGetLastError();
-}
-
 // ---- host launchers -------------------------------------------------------------------------
 
 extern "C" int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st) {

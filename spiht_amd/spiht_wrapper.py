@@ -130,9 +130,15 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
         raise ValueError('image ndim must be 3: c,h,w')
     c, h, w = image.shape
 
+    # wrapper:158-160: the colour model change happens on the GPU, inside level 1 of the transform (color_models.fused)
     color_model = spiht_settings.color_model
     if color_model is not None:
-        image = color_models.convert(image, 'RGB', color_model)
+        if color_model not in color_models.SUPPORTED_MODELS:
+            color_models.convert(image, 'RGB', color_model)  # raises the reference's ValueError
+        if c != 3:
+            raise ValueError("colour conversion needs 3 channels")
+        if image.dtype in (np.float32, np.float16):
+            image = image.astype(np.float64)  # colour-science computes in float64; so does the transform that follows
 
     wid, mid = _wavelet_mode_ids(spiht_settings)
     g = _geometry(h, w, wid, level)
@@ -164,10 +170,11 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
     out = np.empty(max(int(bound.value), 4), dtype=np.uint8)
     nbits, mn = C.c_uint64(), C.c_uint8()
     # one C call: upload, DWT + quantise + pyramid + list coder, stream back (the context keeps its device buffers)
-    _lib.check((L.spiht_encode_image_host_f32 if f32 else L.spiht_encode_image_host_f64)(
-        ctx.handle, C.c_void_p(img.ctypes.data), c, h, w, wid, mid, -1 if level is None else int(level),
-        float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(out.ctypes.data), out.size,
-        C.byref(nbits), C.byref(mn)))
+    with color_models.fused(ctx, color_model):
+        _lib.check((L.spiht_encode_image_host_f32 if f32 else L.spiht_encode_image_host_f64)(
+            ctx.handle, C.c_void_p(img.ctypes.data), c, h, w, wid, mid, -1 if level is None else int(level),
+            float(spiht_settings.quantization_scale), mults_p, max_bits, C.c_void_p(out.ctypes.data), out.size,
+            C.byref(nbits), C.byref(mn)))
     max_n = int(mn.value)
     out = out[:(int(nbits.value) + 7) // 8]
 
@@ -194,12 +201,14 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
         raise OverflowError("out of range integral type conversion attempted")
     mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
     out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
-    _lib.check(_lib.lib().spiht_decode_image_host_f64(
-        _lib.default_context().handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w, wid, mid,
-        -1 if level is None else int(level), float(spiht_settings.quantization_scale), mults_p,
-        C.c_void_p(out.ctypes.data)))
-    if spiht_settings.color_model is not None:
-        out = color_models.convert(out, spiht_settings.color_model, "RGB")
+    ctx = _lib.default_context()
+    if spiht_settings.color_model is not None and c != 3:
+        raise ValueError("colour conversion needs 3 channels")
+    with color_models.fused(ctx, spiht_settings.color_model):  # wrapper:278-279, inside the last level of the inverse transform
+        _lib.check(_lib.lib().spiht_decode_image_host_f64(
+            ctx.handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w, wid, mid,
+            -1 if level is None else int(level), float(spiht_settings.quantization_scale), mults_p,
+            C.c_void_p(out.ctypes.data)))
     return out
 
 
@@ -253,11 +262,10 @@ def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settin
     ctx = _lib.default_context()
     L = _lib.lib()
     out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
-    _lib.check(L.spiht_dequant_idwt_host_f64(ctx.handle, C.c_void_p(rec.ctypes.data), c, h, w, wid, mid,
-                                             -1 if level is None else int(level),
-                                             float(spiht_settings.quantization_scale), mults_p, C.c_void_p(out.ctypes.data)))
-    rec_image = out
-    color_model = spiht_settings.color_model
-    if color_model is not None:
-        rec_image = color_models.convert(rec_image, color_model, "RGB")
-    return rec_image
+    if spiht_settings.color_model is not None and c != 3:
+        raise ValueError("colour conversion needs 3 channels")
+    with color_models.fused(ctx, spiht_settings.color_model):
+        _lib.check(L.spiht_dequant_idwt_host_f64(ctx.handle, C.c_void_p(rec.ctypes.data), c, h, w, wid, mid,
+                                                 -1 if level is None else int(level),
+                                                 float(spiht_settings.quantization_scale), mults_p, C.c_void_p(out.ctypes.data)))
+    return out

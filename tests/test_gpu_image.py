@@ -533,3 +533,57 @@ def test_config3_full_ipt_256_batch():
     for k in range(len(dec_rgb)):
         back = color_models.convert(dec_ipt[k], "IPT", "RGB")
         assert np.abs(dec_rgb[k] - back).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [
+    dict(H=96, W=160, wavelet="bior2.2", mode="reflect", level=3, mults=[50.0, 15.0, 15.0], q=1.0, mb=9000),
+    dict(H=293, W=501, wavelet="bior2.2", mode="reflect", level=None, mults=None, q=50.0, mb=None),      # odd sizes, several strips
+    dict(H=67, W=131, wavelet="bior4.4", mode="symmetric", level=2, mults=[1.0, 0.2, 0.2], q=255.0, mb=20000),
+    dict(H=150, W=145, wavelet="bior6.8", mode="reflect", level=2, mults=None, q=50.0, mb=30000),
+    dict(H=64, W=70, wavelet="bior2.2", mode="zero", level=1, mults=None, q=50.0, mb=5000),               # one level: LL from rec
+    dict(H=40, W=56, wavelet="haar", mode="periodic", level=2, mults=None, q=50.0, mb=4000),
+    dict(H=33, W=47, wavelet="bior2.2", mode="constant", level=1, mults=None, q=50.0, mb=3000),           # smaller than a strip
+    dict(H=300, W=260, wavelet="bior2.2", mode="reflect", level=4, mults=[100.0, 20.0, 20.0], q=1.0, mb=40000),
+])
+def test_fused_colour_equals_separate_colour_pass(cfg):
+    """the colour model change inside level 1 of the transforms (k_dwt1_color / k_idwt1_color) against the
+    same change as a pass of its own (k_color3) around the plain transform: the same function of the same pixels, so
+    streams, start planes and decoded pictures are equal bit for bit."""
+    import spiht_amd
+    from spiht_amd import _lib, color_models
+    from spiht_amd.batch import BatchCodec, DeviceArray
+    H, W, B = cfg["H"], cfg["W"], 3
+    kw = dict(wavelet=cfg["wavelet"], mode=cfg["mode"], quantization_scale=cfg["q"], per_channel_quant_scales=cfg["mults"])
+    s_fused = spiht_amd.SpihtSettings(color_model="IPT", **kw)
+    s_plain = spiht_amd.SpihtSettings(**kw)
+    ctx = _lib.default_context()
+    imgs = np.stack([synth_image(600 + b, 3, H, W) for b in range(B)])
+    imgs[1, :, :5, :7] = 0.0      # zero and saturated patches (the signed power at 0)
+    imgs[2, 0] = 1.0
+    fused, plain = BatchCodec(3, H, W, s_fused, cfg["level"], cfg["mb"], ctx=ctx), BatchCodec(3, H, W, s_plain, cfg["level"], cfg["mb"], ctx=ctx)
+    d = DeviceArray(ctx, imgs.shape, np.float64)
+    d.upload(imgs)
+    color_models.device_convert(ctx, d.ptr, B, H * W, "RGB", "IPT")
+    ctx.synchronize()
+    ipt = d.download()
+    d.free()
+    res_f, res_p = fused.encode(imgs), plain.encode(ipt)
+    for b in range(B):
+        assert res_f[b].max_n == res_p[b].max_n and res_f[b].encoded_bytes == res_p[b].encoded_bytes, (cfg, b)
+    dec_p = plain.decode(res_p)                    # pictures in the coded colour model ...
+    d = DeviceArray(ctx, dec_p.shape, np.float64)
+    d.upload(dec_p)
+    color_models.device_convert(ctx, d.ptr, B, dec_p.shape[2] * dec_p.shape[3], "IPT", "RGB")
+    ctx.synchronize()
+    back = d.download()                            # ... and back to RGB by the pass of its own
+    d.free()
+    dec_f = fused.decode(res_f)
+    assert np.array_equal(dec_f, back), (cfg, float(np.abs(dec_f - back).max()))
+    # the single-image drop-in calls take the same path
+    one = spiht_amd.encode_image(imgs[0], s_fused, cfg["level"], cfg["mb"])
+    assert one.encoded_bytes == res_f[0].encoded_bytes and one.max_n == res_f[0].max_n
+    assert np.array_equal(spiht_amd.decode_image(one, s_fused), dec_f[0])
+    # and the published transform on the host agrees to rounding
+    host = color_models.convert(imgs[0], "RGB", "IPT")
+    assert np.abs(host - ipt[0]).max() < 1e-12

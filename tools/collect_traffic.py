@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic of the HBM-bound kernels from rocprofv3 PMC counters -> profiles/dwt_l1_traffic.json (the forward level-1
-kernel, read by bench.py) and profiles/hbm_traffic_other.json (inverse level 1, pyramid rounds).
+kernel, read by bench.py) and profiles/hbm_traffic_other.json (inverse level 1, significance pyramid: all its kernels).
 
 Run on the GPU box (separate --pmc passes per counter, as MI355X_MICROARCH.md prescribes):
     python tools/collect_traffic.py [batch]
@@ -20,7 +20,8 @@ ITERS = 2
 
 
 def counters(stage, kernel):
-    """per counter: {grid size: mean counter value per launch} of the launches of `kernel` in a run of `stage`"""
+    """per counter: {(kernel name, grid size): mean counter value per launch} of the launches of the kernels whose name
+    contains `kernel` in a run of `stage`"""
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
@@ -32,23 +33,34 @@ def counters(stage, kernel):
         for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(p)):
                 if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
-                    by.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+                    by.setdefault((r["Kernel_Name"], int(r["Grid_Size"])), []).append(float(r["Counter_Value"]))
         res[counter] = {g: sum(v) / len(v) for g, v in by.items()}
     return res
 
 
-def bytes_of(c, grids):
-    rd = sum(c["FETCH_SIZE"][g] for g in grids) * 1024 * 2  # gfx950: FETCH_SIZE counts 64 B per 128 B request
-    wr = sum(c["WRITE_SIZE"][g] for g in grids) * 1024
+def bytes_of(c, keys):
+    rd = sum(c["FETCH_SIZE"][g] for g in keys) * 1024 * 2  # gfx950: FETCH_SIZE counts 64 B per 128 B request
+    wr = sum(c["WRITE_SIZE"][g] for g in keys) * 1024
     return rd, wr
 
 
+def level1(c):
+    """the launches of level 1: per distinct kernel name (the interior-tile and the edge-tile instantiation) the one
+    with the largest grid"""
+    best = {}
+    for (name, grid) in c["FETCH_SIZE"]:
+        if name not in best or grid > best[name]:
+            best[name] = grid
+    return [(name, grid) for name, grid in best.items()]
+
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-# forward level 1: the largest grid of k_dwt_level
+# forward level 1: the largest grid of each k_dwt_level instantiation (interior tiles + edge tiles)
 c = counters("dwt", "k_dwt_level")
-g1 = max(c["FETCH_SIZE"])
-rd, wr = bytes_of(c, [g1])
-out = {"images_per_launch": B, "FETCH_SIZE_KiB_raw": c["FETCH_SIZE"][g1], "WRITE_SIZE_KiB_raw": c["WRITE_SIZE"][g1],
+k1 = level1(c)
+rd, wr = bytes_of(c, k1)
+out = {"images_per_launch": B, "kernels": ["%s grid %d" % k for k in k1],
+       "FETCH_SIZE_KiB_raw": sum(c["FETCH_SIZE"][k] for k in k1), "WRITE_SIZE_KiB_raw": sum(c["WRITE_SIZE"][k] for k in k1),
        "read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr, "hbm_bytes_per_image": (rd + wr) / B,
        "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dwt_l1_traffic.json"), "w"), indent=1)
@@ -56,11 +68,10 @@ print(json.dumps(out))
 # inverse level 1 (largest grid of k_idwt_level) and the pyramid (all rounds of k_pyr_round + k_pyr_ll are small)
 other = {"images_per_launch": B}
 c = counters("idwt", "k_idwt_level")
-g1 = max(c["FETCH_SIZE"])
-rd, wr = bytes_of(c, [g1])
+rd, wr = bytes_of(c, level1(c))
 other["idwt_level1"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
                         "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
-c = counters("pyramid", "k_pyr_round")
+c = counters("pyramid", "k_pyr_")  # k_pyr_12 (depths 1 and 2), k_pyr_round (deeper rounds), k_pyr_ll (root block)
 rd, wr = bytes_of(c, list(c["FETCH_SIZE"]))
 n_coef, n_par = 3 * 1111 * 1949, 3 * (1111 // 2) * (1949 // 2)
 other["pyramid_rounds"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
