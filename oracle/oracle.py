@@ -25,7 +25,8 @@ MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4}
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c", "color_oracle.c",
+                                             "../spiht_amd/csrc/spow.h", "../spiht_amd/csrc/spow_tables.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -202,6 +203,26 @@ def set_codes(x, ll_h, ll_w):
     L.orc_set_codes.argtypes = [C.c_void_p] + [C.c_int64] * 5 + [C.c_void_p] * 3
     _check(L.orc_set_codes(x.ctypes.data, c, h, w, ll_h, ll_w, d.ctypes.data, l.ctypes.data, has.ctypes.data))
     return d, l, has.astype(bool)
+
+
+def spow(x, p):
+    """the colour kernels' signed power sign(x)|x|^p (csrc/spow.h), on the CPU"""
+    L = lib()
+    L.orc_spow.argtypes = [C.c_double, C.c_double]
+    L.orc_spow.restype = C.c_double
+    return L.orc_spow(float(x), float(p))
+
+
+def color3(img, A, M, p):
+    """CPU twin of the GPU's colour model change (k_color3): img float64 [3,...] -> same shape"""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.empty_like(img)
+    A, M = np.ascontiguousarray(A, np.float64), np.ascontiguousarray(M, np.float64)
+    L = lib()
+    L.orc_color3.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_double]
+    L.orc_color3.restype = None
+    L.orc_color3(img.ctypes.data, out.ctypes.data, img.size // 3, A.ctypes.data, M.ctypes.data, float(p))
+    return out
 
 
 def get_offspring(i, j, h, w, ll_h, ll_w):

@@ -497,21 +497,37 @@ __global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint
 #endif  // SPIHT_DIAG
 
 // ---- colour ---------------------------------------------------------------------------------------------------------
+#define SPOW_FN __device__ __forceinline__
+#define SPOW_FMA(a, b, c) fma((a), (b), (c))
+#define SPOW_RINT(a) rint(a)
+#define SPOW_LDEXP(a, n) ldexp((a), (n))
+#define SPOW_TABLE_QUAL __device__ const
+#include "spow_tables.h"
+#include "spow.h"
+
+// the three tables of the power function, copied to LDS by every kernel that converts colours (per-lane table reads)
+struct SpowLds {
+    double inv[SPOW_N], log2c[SPOW_N], exp2t[SPOW_N];
+};
+__device__ __forceinline__ void spow_lds_fill(SpowLds &t, int tid) {  // needs a barrier before the first use
+    if (tid < SPOW_N) { t.inv[tid] = SPOW_INV[tid]; t.log2c[tid] = SPOW_LOG2C[tid]; t.exp2t[tid] = SPOW_EXP2[tid]; }
+}
+
 // One pixel of the colour model change.  Shared by the stand-alone kernel (k_color3) and the fused level-1 kernels, and
-// this file is compiled without multiply-add contraction: the three produce the same bits.  numpy's dot order.
-__device__ __forceinline__ void color3_px(const Color3 &c, double u0, double u1, double u2, double &w0, double &w1, double &w2) {
+// this file is compiled without multiply-add contraction: the three produce the same bits -- and so does the CPU twin
+// oracle/color_oracle.c, which includes the same spow.h.  numpy's dot order.
+__device__ __forceinline__ void color3_px(const Color3 &c, const SpowLds &t, double u0, double u1, double u2, double &w0,
+                                          double &w1, double &w2) {
     double v[3];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
         const double x = (u0 * c.A[3 * r] + u1 * c.A[3 * r + 1]) + u2 * c.A[3 * r + 2];
-#ifdef SPIHT_COLOR_POW   // the device library's pow(): <= 1 ulp, about 250 float64 instruction slots per call
+#ifdef SPIHT_COLOR_POW   // diagnostic: the device library's pow() (<= 1 ulp, about 250 float64 instruction slots per call)
         const double m = pow(fabs(x), c.p);
-#else                    // exp(p log|x|): a few ulp (|p ln x| + 1 units in the last place), a third of the cost -- the colour
-                         // model change is arithmetic-bound (three powers per pixel), and its parity is unpinned anyway
-        const double ax = fabs(x);
-        const double m = ax > 0.0 ? exp(c.p * log(ax)) : 0.0;
-#endif
         v[r] = x < 0.0 ? -m : (x > 0.0 ? m : 0.0);
+#else
+        v[r] = spow_signed(x, c.p, t.inv, t.log2c, t.exp2t);
+#endif
     }
     w0 = (v[0] * c.M[0] + v[1] * c.M[1]) + v[2] * c.M[2];
     w1 = (v[0] * c.M[3] + v[1] * c.M[4]) + v[2] * c.M[5];
@@ -521,10 +537,13 @@ __device__ __forceinline__ void color3_px(const Color3 &c, double u0, double u1,
 // Stand-alone colour model change of a batch of 3-channel float64 images [B,3,npix]; in place allowed.  The checker of
 // the fused kernels, and the path of images that have no transform level.
 __global__ __launch_bounds__(256) void k_color3(const double *__restrict__ in, double *__restrict__ out, size_t npix, Color3 c) {
+    __shared__ SpowLds s_pw;
+    spow_lds_fill(s_pw, threadIdx.x);
+    __syncthreads();
     const size_t img = (size_t)blockIdx.y * 3 * npix;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < npix; t += (size_t)gridDim.x * 256) {
         double w0, w1, w2;
-        color3_px(c, in[img + t], in[img + npix + t], in[img + 2 * npix + t], w0, w1, w2);
+        color3_px(c, s_pw, in[img + t], in[img + npix + t], in[img + 2 * npix + t], w0, w1, w2);
         out[img + t] = w0;
         out[img + npix + t] = w1;
         out[img + 2 * npix + t] = w2;
@@ -549,14 +568,23 @@ extern "C" int spiht_launch_color3(const double *d_in, double *d_out, int B, siz
 // to the axis -1 filter (threads 0..127: aa, ad from the low rows; 128..255: da, dd from the high rows).  One barrier per
 // output row; a pixel is loaded and converted once per strip (F-2 rows of overlap between vertically adjacent strips).
 // Same sums in the same order as k_dwt_level on converted pixels, overhang order included: bit-identical outputs.
-#define C1_PF 2
+#ifndef C1_PF
+#define C1_PF 1   // steps of look-ahead of the raw samples.  256 x 1024x1024: 1 -> 5.6 ms, 2 -> 7.1 (spills at 128 VGPRs wait
+#endif            // for the look-ahead loads in front of them); 3 waves / SIMD without spills: 6.1 - 6.3; 2: 7.7
 #define C1_ROWS 136
+#ifndef C1_WPE
+#define C1_WPE 4
+#endif
 template <int F, uint32_t LOM, uint32_t HIM>
-__global__ __launch_bounds__(256) void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C1_WPE, C1_WPE)))  // 128 VGPRs: left alone the compiler interleaves
+void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       // the six powers of a step over 173 (2 waves / SIMD)
     constexpr int SW = (256 - (F - 2)) / 2;  // output columns per strip: exactly 256 input columns
     constexpr int HC = 128 + 2;
     __shared__ double s_lo[2][3][2][HC];     // [step parity][channel][column parity][column >> 1]
     __shared__ double s_hi[2][3][2][HC];
+    __shared__ SpowLds s_pw;
+    spow_lds_fill(s_pw, threadIdx.x);
+    __syncthreads();
     uint32_t tbx, tby, tbz;
     xcd_tile(gx, gy, a.planes / 3, tbx, tby, tbz);
     const int img = (int)tbz;
@@ -575,7 +603,7 @@ __global__ __launch_bounds__(256) void k_dwt1_color(DwtKArgs a, uint32_t gx, uin
     };
     // "zero" extension pads the CONVERTED signal with zeros (pywt extends what it is given): convert, then zero
     auto cv = [&](int r, double u0, double u1, double u2, double &w0, double &w1, double &w2) {
-        color3_px(a.col, u0, u1, u2, w0, w1, w2);
+        color3_px(a.col, s_pw, u0, u1, u2, w0, w1, w2);
         if (gc < 0 || ext_index(r, a.in_h, a.mode) < 0) { w0 = 0.0; w1 = 0.0; w2 = 0.0; }
     };
     double win[3][F];  // rows 2o+2-F .. 2o+1 of output row o, converted
@@ -882,6 +910,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt1_color(IdwtKArgs a) {
     constexpr int HF = F / 2;
     constexpr int KH = IWC_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IWC_TH / 4 + HF - 1;
     __shared__ double s_b[3][4][KH][KW + 1];  // per channel: aa, ad, da, dd (dequantised)
+    __shared__ SpowLds s_pw;
+    spow_lds_fill(s_pw, threadIdx.x);      // (the barrier after the staging loop below covers it)
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IWC_TH - 1) / IWC_TH, a.planes / 3, tbx, tby, tbz);
     const int img = (int)tbz;
@@ -977,7 +1007,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt1_color(IdwtKArgs a) {
                 }
                 if (m + mp < a.out_h && n < a.out_w) {
                     double w0, w1, w2;
-                    color3_px(a.col, px[0], px[1], px[2], w0, w1, w2);
+                    color3_px(a.col, s_pw, px[0], px[1], px[2], w0, w1, w2);
                     const size_t o = (size_t)(m + mp) * a.out_w + n;
                     out[o] = w0;
                     out[o + opl] = w1;

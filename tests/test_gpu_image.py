@@ -418,6 +418,7 @@ def test_device_colour_conversion_and_config3_batch():
     rng = np.random.default_rng(5)
     x = rng.random((2, 3, 33, 47))
     x[0, :, 0, :5] = 0.0
+    from oracle import oracle as O
     for src, dst in (("RGB", "IPT"), ("IPT", "RGB")):
         inp = x if src == "RGB" else np.stack([color_models.convert(im, "RGB", "IPT") for im in x])
         d = DeviceArray(ctx, inp.shape, np.float64)
@@ -427,6 +428,9 @@ def test_device_colour_conversion_and_config3_batch():
         got = d.download()
         ref = np.stack([color_models.convert(im, src, dst) for im in inp])
         assert np.abs(got - ref).max() < 1e-13, float(np.abs(got - ref).max())
+        # the CPU twin (oracle/color_oracle.c: the same header, the same operations) bit for bit
+        twin = np.stack([O.color3(im, *color_models._params(src, dst)) for im in inp])
+        assert np.array_equal(got, twin), float(np.abs(got - twin).max())
     s = spiht_amd.SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
     H = W = 256
     imgs = np.stack([synth_image(40 + b, 3, H, W) for b in range(2)])

@@ -276,3 +276,41 @@ def test_float32_forward_path_is_bit_identical_to_pywt(oracle):
             assert np.array_equal(arr.view(np.uint32), z[p + "arr"].view(np.uint32))  # every bit of every float
             assert np.array_equal(qa, z[p + "quant"])
         assert hashlib.sha1(np.ascontiguousarray(qa).tobytes()).hexdigest() + ":%dx%dx%d" % qa.shape == str(z[p + "sha1"])
+
+
+def test_colour_power_function_accuracy(oracle):
+    """csrc/spow.h (the colour kernels' sign(x)|x|^p, through its CPU twin oracle/color_oracle.c) against 60-digit
+    arithmetic: under 4 units in the last place for any magnitude, under 1.5 for the forward exponent 0.43; exact
+    special cases.  (Colour parity with the reference is unpinned: colour-science is not available.)"""
+    import math
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+    getcontext().prec = 60
+    rng = np.random.default_rng(1)
+    for p, bound in ((0.43, 1.5), (1 / 0.43, 3.5)):
+        worst = 0.0
+        for _ in range(1500):
+            x = float(rng.choice([rng.uniform(1e-6, 1e-3), rng.uniform(1e-3, 1.0), rng.uniform(1, 4),
+                                  2.0 ** rng.integers(-200, 200) * rng.uniform(1, 2), 1 + rng.uniform(-1e-3, 1e-3)]))
+            got = oracle.spow(x, p)
+            fp, fx = Fraction(p), Fraction(x)
+            ref = (Decimal(fp.numerator) / Decimal(fp.denominator) * (Decimal(fx.numerator) / Decimal(fx.denominator)).ln()).exp()
+            worst = max(worst, float(abs(Decimal(got) - ref) / Decimal(math.ulp(float(ref)))))
+            assert oracle.spow(-x, p) == -got
+        assert worst < bound, (p, worst)
+    assert oracle.spow(0.0, 0.43) == 0.0 and oracle.spow(1.0, 0.43) == 1.0 and oracle.spow(-8.0, 1 / 3.0) == -2.0
+    assert oracle.spow(1e308, 2.3) == float("inf") and 0.0 < oracle.spow(5e-324, 0.43) < 1e-130
+
+
+def test_colour_twin_matches_published_transform(oracle):
+    """the CPU twin of the GPU's colour model change against the host implementation of the published IPT transform
+    (numpy's pow): agreement to rounding, and the round trip RGB -> IPT -> RGB"""
+    from spiht_amd import color_models
+    rng = np.random.default_rng(2)
+    img = rng.random((3, 40, 50))
+    img[:, 0, :4] = 0.0
+    A, M, p = color_models._params("RGB", "IPT")
+    ipt = oracle.color3(img, A, M, p)
+    assert np.abs(ipt - color_models.convert(img, "RGB", "IPT")).max() < 2e-15
+    Ai, Mi, pi = color_models._params("IPT", "RGB")
+    assert np.abs(oracle.color3(ipt, Ai, Mi, pi) - img).max() < 1e-13
