@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C1_WPE, C1_
 void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       // the six powers of a step over 173 (2 waves / SIMD)
     constexpr int SW = (256 - (F - 2)) / 2;  // output columns per strip: exactly 256 input columns
     constexpr int HC = 128 + 2;
-    __shared__ double s_lo[2][3][2][HC];     // [step parity][channel][column parity][column >> 1]
+    __shared__ double s_lo[2][3][2][HC];     // [output row parity][channel][column parity][column >> 1]
     __shared__ double s_hi[2][3][2][HC];
     __shared__ SpowLds s_pw;
     spow_lds_fill(s_pw, threadIdx.x);
@@ -646,8 +646,8 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
                         if ((LOM >> j) & 1u) sl += a.lo[j] * win[ch][F - 1 - j];
                         if ((HIM >> j) & 1u) shh += a.hi[j] * win[ch][F - 1 - j];
                     }
-                    s_lo[u & 1][ch][par][hc] = sl;
-                    s_hi[u & 1][ch][par][hc] = shh;
+                    s_lo[o & 1][ch][par][hc] = sl;
+                    s_hi[o & 1][ch][par][hc] = shh;
                 }
             } else {  // bottom overhang: PyWavelets' order (k_dwt_level); the window element is picked with selects
                 const int jb = 2 * o + 1 - a.in_h;
@@ -662,8 +662,8 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
                         sl += a.lo[j] * v;
                         shh += a.hi[j] * v;
                     }
-                    s_lo[u & 1][ch][par][hc] = sl;
-                    s_hi[u & 1][ch][par][hc] = shh;
+                    s_lo[o & 1][ch][par][hc] = sl;
+                    s_hi[o & 1][ch][par][hc] = shh;
                 }
             }
             // slide the windows: the two rows this step brings in are converted now, their successors requested
@@ -681,7 +681,7 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
             if (wr && o < ob) {
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
-                    const double(*src)[HC] = role ? s_hi[u & 1][ch] : s_lo[u & 1][ch];
+                    const double(*src)[HC] = role ? s_hi[o & 1][ch] : s_lo[o & 1][ch];
                     double r0 = 0.0, r1 = 0.0;  // role 0: aa, ad   role 1: da, dd
                     if (ow < a.ov_w) {
 #pragma unroll

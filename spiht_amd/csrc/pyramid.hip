@@ -159,6 +159,25 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
     uint8_t *__restrict__ dm = a.dmsb + base;
     uint8_t *__restrict__ lm = a.lmsb + base;
     const uint32_t ci = 2 * qi, cj = 4 * t, gi = 4 * qi, gj = 8 * t;
+    {
+        // Nothing to do here when neither node has depth 2 and none of their offspring has depth 1 (a pair deeper in
+        // the tree: rounds >= 3 take it): leave before the loads -- those offspring and grand-offspring are read by
+        // the threads of THEIR depth, and reading them here as well cost 10 % more traffic than the array holds.
+        bool any = false;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t r = ci + rr, c = cj + q;
+                any = any || (2 * r + 1 < h && 2 * c + 1 < w && !((uint64_t)4 * r + 1 < h && (uint64_t)4 * c + 1 < w));
+            }
+#pragma unroll
+        for (int pr = 0; pr < 2; pr++) {
+            const uint32_t qj = 2 * t + pr;
+            any = any || ((uint64_t)4 * qj + 1 < w && !((uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w));
+        }
+        if (!any) return;
+    }
     int32_t xc[2][4], xg[4][8];
     if (gi + 3 < h && gj + 7 < w) {  // everything in bounds: vector loads, all issued before the first use
         const i4u c0 = *reinterpret_cast<const i4u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i4u *>(x + (size_t)(ci + 1) * w + cj);

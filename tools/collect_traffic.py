@@ -55,8 +55,8 @@ def level1(c):
 
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-# forward level 1: the largest grid of each k_dwt_level instantiation (interior tiles + edge tiles)
-c = counters("dwt", "k_dwt_level")
+# forward level 1: the largest grid of k_dwt_level and of the overhang fix-up kernel behind it (k_dwt_edge)
+c = counters("dwt", "k_dwt_")
 k1 = level1(c)
 rd, wr = bytes_of(c, k1)
 out = {"images_per_launch": B, "kernels": ["%s grid %d" % k for k in k1],
