@@ -166,31 +166,30 @@ class OverlappedCodec:
 
     The transform / pyramid / inverse-transform passes are HBM-bound; the list coder is latency-bound and leaves the
     HBM idle.  Context H runs the former, contexts L0 / L1 (alternating by batch) the latter, ordered with events only
-    (the host never blocks):
+    (the host never blocks), so while a batch is list-coded, H already transforms the next one and inverse-transforms
+    the previous one (`pair="inverse"`, the default):
 
-        H:  [X(i-1) done] I(i-1)         A(i+1)                  [X(i) done] I(i)          A(i+2) ...
-        L:  [A(i), X(i-1) done] U E(i)   [I(i-1) done] X(i)      [A(i+1), X(i) done] U E(i+1)   [I(i) done] X(i+1) ...
+        H:  A(i)               [X(i-1) done] I(i-1)   A(i+1)                 [X(i) done] I(i) ...
+        L:  [A(i), I(i-2) done] U(i-2) E(i) X(i)              [A(i+1), I(i-1) done] U(i-1) E(i+1) X(i+1) ...
 
     A = DWT + quantise + pyramid, E / X = encoder / decoder list kernels, I = dequantise + inverse DWT, U = put the
     zeros back into the coefficient array X(i-2) scattered into (spiht_unscatter_lists_batch_i32: through the
     decoder's lists, which is why each of the two arrays has its own list-coding context) -- a full zero-fill per
     batch would add 6.6 GB of writes to the HBM-bound side.  E(i+1) is ordered after X(i), so list kernels never run
-    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).
+    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).  Results are
+    bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder output are
+    double-buffered.
 
-    What shares the GPU with what is chosen from measurements.  Resident decoder workgroups (12
-    wavefronts, 96 VGPRs) leave an HBM-bound kernel three instead of six or seven workgroups per CU.  The forward
-    transform lives with that -- its threads keep 28 loads in flight each: X and A side by side take 11.5 ms each
-    (7.9 and 7.8 alone) -- the inverse transform does not (level 1: 8.6 instead of 4.0 ms, and it still slows the decoder
-    to 10.1).  `pair="forward"` therefore holds the decoder X(i) back until the inverse transform of the previous
-    batch has finished: it then runs beside A(i+1), and I(i-1) meets only the short encoder kernel.  Measured: no better
-    (20.6 ms per step against 20.2 for `pair="inverse"`, X(i) right behind E(i) and beside I(i-1), which the diagram above
-    does NOT show: there X(i) follows E(i) directly and A runs mostly alone) -- whichever transform shares the GPU with
-    the decoder takes twice its time.  `pair="inverse"` is the default.
-
-    Results are bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder
-    output are double-buffered.  `split_inverse` queues the coarse levels of the inverse transform (level .. 2) behind
-    the decoder on the list-coding stream instead (measured: no gain, kept for experiments).  `between` (optional
-    callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream gather of a multi-GPU job."""
+    Resident decoder workgroups (12 wavefronts, 96 VGPRs) leave an HBM-bound kernel three instead of six or seven
+    workgroups per CU: whichever transform shares the GPU with the decoder takes about twice its time.  Variants,
+    measured at 256 x 1080p, none better than the default's 20.2 ms per step:
+      pair="forward"    X(i) waits for I(i-1), so it runs beside A(i+1) and I(i-1) meets only the encoder kernel: 20.6
+      split_inverse     the coarse levels of I(i) (level .. 2) behind X(i) on the list-coding stream: 21.1 (the encoder
+                        kernel of the next batch then waits for room on CUs full of transform workgroups)
+      l_priority        high stream priority for the list-coding contexts: no change
+      e_first           encoder kernel queued before the unscatter: 21.8
+    `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
+    gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
     def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False):
         self.codec, self.B = codec, int(B)
