@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--split-inverse", type=int, default=0, help="experiment: coarse inverse levels on the list-coding stream")
     ap.add_argument("--l-priority", type=int, default=0, help="experiment: stream priority of the list-coding contexts")
     ap.add_argument("--e-first", type=int, default=0, help="experiment: encoder kernel queued before the unscatter")
+    ap.add_argument("--u-early", type=int, default=0, help="experiment: unscatter right behind the inverse transform")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -257,7 +258,7 @@ def main():
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
         from spiht_amd.batch import OverlappedCodec
         pipe = OverlappedCodec(codec, B, pair=args.pair, split_inverse=bool(args.split_inverse), l_priority=args.l_priority,
-                               e_first=bool(args.e_first))
+                               e_first=bool(args.e_first), u_early=bool(args.u_early))
         ctxs.extend(pipe.Ls)
 
     def step():

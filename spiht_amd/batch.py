@@ -191,7 +191,7 @@ class OverlappedCodec:
     `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
-    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False):
+    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=False):
         self.codec, self.B = codec, int(B)
         if pair not in ("forward", "inverse"):
             raise ValueError("pair must be 'forward' or 'inverse'")
@@ -200,6 +200,8 @@ class OverlappedCodec:
         self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device, l_priority),
                    _lib.Context(self.H.device, l_priority)]
         self.e_first = bool(e_first)  # experiment: encoder kernel queued before the unscatter
+        self.u_early = bool(u_early)  # the unscatter of a batch right behind its inverse transform (off the next list-coding chain)
+        self._unscattered = [True, True]
         self.L = self.Ls[0]
         g = codec.geom
         n = codec.c * g["enc_h"] * g["enc_w"]
@@ -262,9 +264,10 @@ class OverlappedCodec:
             Lc.wait_event(self.ev_d[s ^ 1])
         Lc.wait_event(self.ev_a[s])
         def unscatter():
-            if self.used[s]:
+            if self.used[s] and not self._unscattered[s]:
                 Lc.wait_event(self.ev_i[s])
                 _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
+                self._unscattered[s] = True
         if not self.e_first:
             unscatter()
         # ... and list coding, after the previous batch's decoder on the other context
@@ -292,9 +295,16 @@ class OverlappedCodec:
                 vp(self.approx[s].ptr)))
         Lc.record(self.ev_d[s])
         self.used[s] = True
+        self._unscattered[s] = False
         # H: back half of the previous batch's decoder (pair="inverse": beside this batch's decoder)
         if self._pending is not None:
             self._idwt(*self._pending)
+            if self.u_early:  # ... and the zeros back into its array as soon as that has read it, on ITS list-coding context
+                sp = self._pending[0]
+                Lp = self.Ls[sp]
+                Lp.wait_event(self.ev_i[sp])
+                _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lp.handle, vp(self.rec[sp].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
+                self._unscattered[sp] = True
         self._pending = (s, d_img_out)
         self.i += 1
 

@@ -899,6 +899,147 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
     }
 }
 
+// ---- the inverse level as persistent workgroups that fetch one tile ahead ---------------------------------------------
+// k_idwt_level is a workgroup per tile: request the tile's bands, wait a memory latency, filter, store, exit.  With few
+// workgroups resident on a CU -- three when a list decoder lives there too (the pipelined schedule of
+// spiht_amd/batch.py) -- a CU has three tiles in flight and the level is bound by that latency, not by bytes: 8.5 instead
+// of 4.0 ms for level 1 of 256 1080p images, and not reading the detail bands at all changed nothing.
+// Here a workgroup walks a sequence of tiles and requests tile k+1's samples (into registers: 15 per thread) before it
+// filters and stores tile k, so the latency of k+1 runs under the work of k.  The barriers are bare s_barrier behind an
+// lgkmcnt wait: __syncthreads() would wait for the loads in flight as well.  Same arithmetic in the same order as
+// k_idwt_level: bit-identical output.  grid: IWP_WG workgroups per CU at most; tiles dealt XCD-contiguously.
+#ifndef IWP_WG
+#define IWP_WG 4
+#endif
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define IWP_ATTR
+template <int F, uint32_t LOM, uint32_t HIM, bool FIRST>  // FIRST: coarsest level, the approximation comes from the packed array
+__global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy) {
+    constexpr int HF = F / 2;
+    constexpr int KH = IW_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IW_TH / 4 + HF - 1;
+    constexpr int NE = (KH * KW + DW_BLOCK - 1) / DW_BLOCK;  // staged elements per thread
+    __shared__ double s_b[4][KH][KW + 1];                    // aa, ad, da, dd (dequantised)
+    const int tid = threadIdx.x;
+    // this workgroup's tiles: workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous tile range
+    // [x*q + min(x, r), ...) and its workgroups (every 8th) take the tiles of that range in turn
+    const uint32_t nt = gx * gy * (uint32_t)a.planes, G = gridDim.x;
+    const uint32_t x = blockIdx.x & 7u, q = nt >> 3, r8 = nt & 7u;
+    const uint32_t base = x * q + (x < r8 ? x : r8), cnt = q + (x < r8 ? 1u : 0u);
+    const uint32_t per = (G + 7u - x) >> 3;  // workgroups of this launch on XCD x
+    uint32_t k = blockIdx.x >> 3;            // position of the next tile in the XCD's range
+
+    struct Stage {  // the samples of one tile on their way from memory: 15 registers per thread
+        int32_t rad[NE], rda[NE], rdd[NE], raa[NE];
+        double vaa[NE];
+    };
+    auto request = [&](Stage &g, uint32_t T) {  // the loads of tile T (nothing waits for them here)
+        const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
+        const int kh0 = (int)(by * IW_TH) / 2, kw0 = (int)(bx * IW_TW) / 2;
+        const int32_t *__restrict__ rec = a.rec + (size_t)plane * a.enc_h * a.enc_w;
+        const double *__restrict__ ain = FIRST ? nullptr : a.a_in + (size_t)plane * a.a_h * a.a_w;
+        // unconditional loads from clamped positions (a branch around a load makes the compiler wait for it at the
+        // join); what lies outside the band is zeroed when the samples go to LDS
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int p = min(tid + e * DW_BLOCK, KH * KW - 1);
+            const int rr = p / KW, cidx = p - rr * KW;
+            const int bi = min(kh0 + rr, a.band_h - 1), bj = min(kw0 + cidx, a.band_w - 1);
+            g.rad[e] = rec[(size_t)bi * a.enc_w + a.off_w + bj];
+            g.rda[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
+            g.rdd[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            if (FIRST) { g.raa[e] = rec[(size_t)bi * a.enc_w + bj]; g.vaa[e] = 0.0; }
+            else { g.vaa[e] = ain[(size_t)bi * a.a_w + bj]; g.raa[e] = 0; }
+        }
+    };
+    // taps of axis -1 for this thread's column parity (n0 is even: the parity is the same in every tile)
+    const int nn = tid & (IW_TW - 1), half = tid / IW_TW, np = nn & 1, cl = nn / 2;
+    double tlo[HF], thi[HF];
+#pragma unroll
+    for (int s2 = 0; s2 < HF; s2++) {
+        tlo[s2] = a.lo[np + F - 2 - 2 * s2];
+        thi[s2] = a.hi[np + F - 2 - 2 * s2];
+    }
+    const bool has_m = a.mults != nullptr;
+    // one tile: its samples (in g) -> LDS, then g is free and takes the loads of the next tile; filter; store
+    auto tile = [&](Stage &g, uint32_t kk) {
+        const uint32_t T = base + kk;
+        const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
+        const int kh0s = (int)(by * IW_TH) / 2, kw0s = (int)(bx * IW_TW) / 2;
+        const double mk = has_m ? a.mults[plane % (uint32_t)a.c] : 1.0;
+        const bool zero_ok = (!has_m || mk > 0.0) && a.q > 0.0;  // 0/m/q == +0.0 exactly: skip the divisions
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const int p = tid + e * DW_BLOCK;
+            if (p < KH * KW) {
+                const int rr = p / KW, cidx = p - rr * KW;
+                const bool in = kh0s + rr < a.band_h && kw0s + cidx < a.band_w;
+                const double va = FIRST ? ((g.raa[e] == 0 && zero_ok) ? 0.0 : dequant(g.raa[e], mk, a.q, has_m)) : g.vaa[e];
+                s_b[0][rr][cidx] = in ? va : 0.0;
+                s_b[1][rr][cidx] = (!in || (g.rad[e] == 0 && zero_ok)) ? 0.0 : dequant(g.rad[e], mk, a.q, has_m);
+                s_b[2][rr][cidx] = (!in || (g.rda[e] == 0 && zero_ok)) ? 0.0 : dequant(g.rda[e], mk, a.q, has_m);
+                s_b[3][rr][cidx] = (!in || (g.rdd[e] == 0 && zero_ok)) ? 0.0 : dequant(g.rdd[e], mk, a.q, has_m);
+            }
+        }
+        if (kk + per < cnt) request(g, base + kk + per);
+        lds_barrier();
+        // ---- thread = (output column nn, half): as k_idwt_level ----
+        const int m0 = (int)by * IW_TH, n0 = (int)bx * IW_TW, kh0 = m0 / 2;
+        const int n = n0 + nn;
+        double wl[HF], wh[HF];
+#pragma unroll
+        for (int s2 = 0; s2 < HF; s2++) { wl[s2] = 0.0; wh[s2] = 0.0; }
+        double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
+        const int rbase = half * (IW_TH / 4);
+#pragma unroll
+        for (int rr = 0; rr < KHH; rr++) {
+            const int r = rbase + rr;
+            double ta = 0.0, td = 0.0, ua = 0.0, ud = 0.0;
+#pragma unroll
+            for (int j = 0; j < HF; j++) {
+                const int s2 = HF - 1 - j;
+                constexpr uint32_t PAIR = 3u;
+                const bool lnz = ((LOM >> (F - 2 - 2 * s2)) & PAIR) != 0, hnz = ((HIM >> (F - 2 - 2 * s2)) & PAIR) != 0;
+                if (lnz) {
+                    ta += s_b[0][r][cl + s2] * tlo[s2];
+                    ua += s_b[2][r][cl + s2] * tlo[s2];
+                }
+                if (hnz) {
+                    td += s_b[1][r][cl + s2] * thi[s2];
+                    ud += s_b[3][r][cl + s2] * thi[s2];
+                }
+            }
+            const double tl = (0.0 + ta) + td, th = (0.0 + ua) + ud;
+#pragma unroll
+            for (int s2 = 0; s2 < HF - 1; s2++) { wl[s2] = wl[s2 + 1]; wh[s2] = wh[s2 + 1]; }
+            wl[HF - 1] = tl;
+            wh[HF - 1] = th;
+            if (rr >= HF - 1) {
+                const int m = 2 * (kh0 + r - (HF - 1));
+#pragma unroll
+                for (int mp = 0; mp < 2; mp++) {
+                    double sa = 0.0, sd = 0.0;
+#pragma unroll
+                    for (int j = 0; j < HF; j++) {
+                        const int s2 = HF - 1 - j;
+                        const bool lnz = (LOM >> (mp + F - 2 - 2 * s2)) & 1u, hnz = (HIM >> (mp + F - 2 - 2 * s2)) & 1u;
+                        if (lnz) sa += wl[s2] * a.lo[mp + F - 2 - 2 * s2];
+                        if (hnz) sd += wh[s2] * a.hi[mp + F - 2 - 2 * s2];
+                    }
+                    const double sacc = (0.0 + sa) + sd;
+                    if (m + mp < a.out_h && n < a.out_w) out[(size_t)(m + mp) * a.out_w + n] = sacc;
+                }
+            }
+        }
+        lds_barrier();  // every wave has read the tile before the next one is written over it
+    };
+    // One tile ahead.  (Two ahead -- a second register set, 116 VGPRs -- leaves room for ONE such workgroup per CU beside
+    // a decoder instead of two and was slower there: 9.2-10.6 instead of 7.2 ms for level 1.)
+    Stage g0;
+    if (k < cnt) request(g0, base + k);
+    for (; k < cnt; k += per) tile(g0, k);
+}
+
 // ---- level 1 of the inverse transform of a 3-channel image with the colour model change on its stores ------------
 // k_idwt_level for the three channels of a tile at once (same staging, same sums in the same order), so that the three
 // values of an output pixel meet in one thread, which converts them (color3_px: three pow() per pixel) and stores the
@@ -1082,7 +1223,23 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((k_idwt1_color<F, LOM, HIM>), dim3(ntc), dim3(DW_BLOCK), 0, st, a);
         return (int)hipGetLastError();
     }
-    uint32_t nt = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW) * (uint32_t)((a.out_h + IW_TH - 1) / IW_TH) * (uint32_t)planes;
+    const uint32_t gx = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW), gy = (uint32_t)((a.out_h + IW_TH - 1) / IW_TH);
+    const uint32_t nt = gx * gy * (uint32_t)planes;
+    static const int pf = [] { const char *e = getenv("SPIHT_IDWT_PF"); return e ? atoi(e) : 1; }();
+    static const int num_cu = [] {
+        int dev = 0, n = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        return n;
+    }();
+    // a level with several tiles per workgroup slot: persistent workgroups that fetch a tile ahead
+    static const uint32_t pf_min = [] { const char *e = getenv("SPIHT_IDWT_PF_MIN"); return e ? (uint32_t)atol(e) : 20000u; }();
+    if (pf && nt >= pf_min) {
+        const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : IWP_WG));
+        if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy);
+        else hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL((k_idwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
 }
