@@ -94,10 +94,122 @@ def exchange_id(rank, world, payload=None, addr=None, port=None, timeout=300.0):
         time.sleep(0.2)
 
 
+class HostGroup:
+    """The job's ranks as a star of TCP connections to rank 0 (same ports as `exchange_id`): the host-side channel for what
+    must work even where RCCL does not come up -- handing out the RCCL id, the barrier around the timed region, the
+    maximum of the ranks' times.  Payloads are a few bytes; no data of the path travels here."""
+
+    def __init__(self, rank=None, world=None, addr=None, port=None, timeout=300.0):
+        self.rank = int(os.environ.get("RANK", "0")) if rank is None else int(rank)
+        self.world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else int(world)
+        self.peers, self.sock = {}, None
+        if self.world == 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
+        hello = _MAGIC + struct.pack("<II", self.world, 1)
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = None
+            for k in range(1, _PORT_SPAN + 1):
+                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                try:
+                    s.bind(("", base + k))
+                    s.listen(self.world)
+                    srv = s
+                    break
+                except OSError:
+                    s.close()
+            if srv is None:
+                raise RuntimeError("no free port in %d..%d for the job's host channel" % (base + 1, base + _PORT_SPAN))
+            srv.settimeout(1.0)
+            try:
+                while len(self.peers) < self.world - 1:
+                    if time.time() > deadline:
+                        raise TimeoutError("host channel: %d of %d peers arrived" % (len(self.peers), self.world - 1))
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        continue
+                    try:
+                        conn.settimeout(5.0)
+                        head = _recv_exact(conn, len(hello) + 4)
+                        (r,) = struct.unpack("<I", head[len(hello):])
+                        if head[:len(hello)] != hello or not 0 < r < self.world or r in self.peers:
+                            conn.close()
+                            continue
+                        conn.sendall(_MAGIC)
+                        conn.settimeout(timeout)
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        self.peers[r] = conn
+                    except (OSError, ConnectionError):
+                        conn.close()
+            finally:
+                srv.close()
+            return
+        while self.sock is None:
+            for k in range(1, _PORT_SPAN + 1):
+                try:
+                    c = socket.create_connection((addr, base + k), timeout=2.0)
+                    c.settimeout(5.0)
+                    c.sendall(hello + struct.pack("<I", self.rank))
+                    if _recv_exact(c, len(_MAGIC)) != _MAGIC:
+                        c.close()
+                        continue
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.sock = c
+                    break
+                except (OSError, ConnectionError):
+                    continue
+            if self.sock is None:
+                if time.time() > deadline:
+                    raise TimeoutError("host channel: rank 0 not reachable on %s:%d..%d" % (addr, base + 1, base + _PORT_SPAN))
+                time.sleep(0.2)
+
+    def _exchange(self, mine, combine):
+        """every rank contributes `mine` (bytes); rank 0 combines the list (rank order) into one reply for all"""
+        if self.world == 1:
+            return combine([mine])
+        if self.rank == 0:
+            parts = [mine] + [None] * (self.world - 1)
+            for r, c in self.peers.items():
+                (n,) = struct.unpack("<I", _recv_exact(c, 4))
+                parts[r] = _recv_exact(c, n)
+            out = combine(parts)
+            for c in self.peers.values():
+                c.sendall(struct.pack("<I", len(out)) + out)
+            return out
+        self.sock.sendall(struct.pack("<I", len(mine)) + mine)
+        (n,) = struct.unpack("<I", _recv_exact(self.sock, 4))
+        return _recv_exact(self.sock, n)
+
+    def barrier(self):
+        self._exchange(b"", lambda parts: b"")
+
+    def max(self, value):
+        out = self._exchange(struct.pack("<d", float(value)), lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
+        return struct.unpack("<d", out)[0]
+
+    def bcast(self, payload=None):
+        """rank 0's payload to every rank"""
+        return self._exchange(payload if self.rank == 0 else b"", lambda parts: parts[0])
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.sock] if self.sock is not None else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.sock = {}, None
+
+
 class Comm:
     """The job's RCCL communicator (spiht_comm of include/spiht_hip.h) on one context's GPU."""
 
-    def __init__(self, ctx, rank=None, world=None):
+    def __init__(self, ctx, rank=None, world=None, group=None):
+        """group: a HostGroup to carry rank 0's id to the others (else a one-shot exchange_id)"""
         from . import _lib
         self._lib = _lib.lib()
         self._check = _lib.check
@@ -106,9 +218,16 @@ class Comm:
         ident = None
         if self.rank == 0:
             buf = (C.c_uint8 * 128)()
-            self._check(self._lib.spiht_comm_unique_id(buf))
-            ident = bytes(buf)
-        ident = exchange_id(self.rank, self.world, ident)
+            try:
+                self._check(self._lib.spiht_comm_unique_id(buf))
+                ident = bytes(buf)
+            except Exception:
+                if group is None:
+                    raise
+                ident = b""  # the others must not wait for an id that will not come
+        ident = group.bcast(ident) if group is not None else exchange_id(self.rank, self.world, ident)
+        if len(ident) != 128:
+            raise RuntimeError("rank 0 could not create the RCCL id")
         h = C.c_void_p()
         self._check(self._lib.spiht_comm_create(ctx.handle, (C.c_uint8 * 128).from_buffer_copy(ident), self.world,
                                                 self.rank, C.byref(h)))

@@ -150,3 +150,35 @@ def test_id_exchange_two_and_three_ranks():
         if blocker is not None:
             blocker.close()
         assert res == [(r, True) for r in range(world)], res
+
+
+def _group_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        from spiht_amd.dist import HostGroup
+        g = HostGroup(rank, world, addr="127.0.0.1", port=port, timeout=60)
+        g.barrier()
+        m = g.max(rank * 1.5)
+        b = g.bcast(bytes(range(128)) if rank == 0 else None)
+        m2 = g.max(-float(rank))
+        g.barrier()
+        g.close()
+        q.put((rank, m, m2, b == bytes(range(128))))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+
+
+def test_host_group_barrier_max_bcast():
+    """The job's host channel (spiht_amd/dist.py:HostGroup: barrier around the timed region, maximum of the ranks' times,
+    rank 0's RCCL id to everyone) with four ranks that start in scrambled order."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    world, port = 4, _free_port()
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_group_worker, args=(r, world, port, q)) for r in (3, 1, 0, 2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, 4.5, 0.0, True) for r in range(world)], res

@@ -61,3 +61,10 @@ def test_bench_under_a_launcher_gathers_through_rccl():
         assert d["n_gpus"] == 1 and d["check"]["gather_rows_match"] is True
         assert d["config"]["gather"]["world"] == 1 and d["config"]["gather"]["rccl_version"] > 0
         assert d["check"]["nbits_all_equal_budget"] and d["cpu_baseline"] is None
+    # should RCCL not come up, the job still runs (host channel for the barrier and the times) and says so
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--cpu-sample", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(env, SPIHT_BENCH_NO_RCCL="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["check"]["gather_rows_match"] is None and "failed" in d["config"]["gather"] and d["value"] > 0

@@ -283,6 +283,44 @@ def test_overlapped_codec_matches_fused(oracle, shape):
         assert np.array_equal(rec[:, :, :ref.shape[2], :ref.shape[3]], ref)
 
 
+@pytest.mark.parametrize("opts", [dict(pair="forward"), dict(split_inverse=True), dict(pair="forward", split_inverse=True),
+                                  dict(u_early=True), dict(e_first=True, l_priority=1)])
+def test_overlapped_codec_schedule_variants(opts):
+    """Every arrangement of the pipelined schedule (OverlappedCodec: what the decoder shares the GPU with, the inverse
+    transform in two parts -- spiht_idwt_coarse_batch_f64 / spiht_idwt_level1_batch_f64 --, where the unscatter goes,
+    stream priorities) codes the same streams and pictures as the fused calls, with and without a colour model."""
+    import spiht_amd
+    from spiht_amd import _lib
+    from spiht_amd.batch import BatchCodec, DeviceArray, OverlappedCodec
+    ctx = _lib.default_context()
+    for settings, (c, H, W, B, mb, steps, level) in (
+            (spiht_amd.SpihtSettings(), (3, 130, 200, 4, 20000, 5, 4)),
+            (spiht_amd.SpihtSettings(), (1, 61, 47, 3, 2500, 4, 1)),       # one level: no coarse part
+            (spiht_amd.SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0]),
+             (3, 96, 136, 3, 9000, 4, 3))):
+        codec = BatchCodec(c, H, W, settings, level, mb, ctx=ctx)
+        g = codec.geom
+        ov = OverlappedCodec(codec, B, **opts)
+        imgs = [np.stack([synth_image(700 + 10 * st + b, c, H, W) for b in range(B)]) for st in range(steps)]
+        d_imgs = [DeviceArray(ctx, (B, c, H, W), np.float64) for _ in range(steps)]
+        d_recs = [DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64) for _ in range(steps)]
+        d_outs = [DeviceArray(ctx, (B, codec.slot_stride), np.uint8) for _ in range(steps)]
+        d_nbits = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
+        d_maxn = [DeviceArray(ctx, (B,), np.uint8) for _ in range(steps)]
+        d_nbytes = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
+        for st in range(steps):
+            d_imgs[st].upload(imgs[st])
+        for st in range(steps):
+            ov.submit(d_imgs[st].ptr, d_outs[st].ptr, d_nbits[st].ptr, d_maxn[st].ptr, d_nbytes[st].ptr, d_recs[st].ptr)
+        ov.synchronize()
+        for st in range(steps):
+            res = codec.encode(imgs[st])
+            nb, out, mn = d_nbits[st].download(), d_outs[st].download(), d_maxn[st].download()
+            for b in range(B):
+                assert int(mn[b]) == res[b].max_n and out[b, :(int(nb[b]) + 7) // 8].tobytes() == res[b].encoded_bytes, (opts, st, b)
+            assert np.array_equal(d_recs[st].download(), np.stack(codec.decode(res))), (opts, st)
+
+
 def test_progressive_prefixes_in_one_batch(oracle):
     """make_gif.py:46-61: byte prefixes of one stream, decoded together; quality never gets worse"""
     import spiht_amd
