@@ -15,9 +15,9 @@
 //
 // A node (i,j) outside the root block has a sub-tree of depth >= d iff i*2^d+1 < h and
 // j*2^d+1 < w (its top-left descendant chain is the longest).  k_pyr_12 handles the nodes of depth 1 and 2 in one
-// launch (15/16 of the array is read there: a thread owns two depth->=2 nodes, loads their 2x4 children and 4x8
-// grandchildren up front -- ten 16-byte loads in flight -- and writes the codes of the children's row as one
-// 4-byte store); launch `round` d >= 3 handles the nodes of depth exactly d, whose offspring were finished before.
+// launch (15/16 of the array is read there: a thread owns one depth->=2 node, loads its 2x2 children and 4x4
+// grandchildren up front, and a lane pair writes the codes of the children's row as one 4-byte store); launch
+// `round` d >= 3 handles the nodes of depth exactly d, whose offspring were finished before.
 // HBM-bound: 4 B read per coefficient, ~1/4 + 1/16 B written.
 #include "common.h"
 
@@ -131,14 +131,17 @@ __global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a, uint32_t gx, uint3
     if (v1) { dm[i * w + j1] = (uint8_t)dcode[1]; lm[i * w + j1] = (uint8_t)lcode[1]; }
 }
 
-// Depth 1 and depth 2 in one pass.  Thread = two horizontally adjacent nodes q0 = (qi, 2t), q1 = (qi, 2t+1) with
-// 4*qi+1 < h (every node with offspring whose offspring have offspring is such a q or lies above one): their 2x4 block of
-// children o and 4x8 block of grandchildren are loaded first.  Then
+// Depth 1 and depth 2 in one pass.  Thread = one node q = (qi, qj) with 4*qi+1 < h (every node with offspring whose
+// offspring have offspring is such a q or lies above one): its 2x2 block of children o and 4x4 block of grandchildren
+// are loaded first -- four 16-byte rows and two 8-byte rows, and consecutive lanes read consecutive memory, so one
+// wave-instruction covers 1 KB contiguously (a two-nodes-per-thread form, which reads every line with two instructions,
+// measured 5 % slower).  Then
 //   * every child o of depth exactly 1 (offspring, no grand-offspring) gets D(o) = max code of its four offspring
 //     (L(o) is empty and is never looked up: a type-B entry needs grand-offspring, encoder_decoder.rs:7-12, :258);
 //   * q itself, when its depth is exactly 2, gets D(q) = max over its offspring of max(code, D) and L(q) = max D.
-// Nodes of the root block are left to k_pyr_ll.  1-D grid, XCD-contiguous tile order;
-// tiles: (ceil(npairs/64), ceil(rows/4), B*c), block (64,4).
+// Lane pairs exchange their byte results with one cross-lane read each and the even lane stores for both (one 4-byte
+// store per offspring row, 2-byte stores for the pair of q).  Nodes of the root block are left to k_pyr_ll.
+// 1-D grid, XCD-contiguous tile order; tiles: (ceil(cols/64), ceil(rows/4), B*c), block (64,4).
 __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t gy, uint32_t gz) {
     const Geom g = a.g;
     uint32_t bx, by, bz;
@@ -151,119 +154,100 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
         by = t2 % gy;
         bz = t2 / gy;
     }
-    const uint32_t t = bx * 64 + threadIdx.x, qi = by * 4 + threadIdx.y;
+    const uint32_t qj = bx * 64 + threadIdx.x, qi = by * 4 + threadIdx.y;
     const uint32_t h = (uint32_t)g.h, w = (uint32_t)g.w, lh = (uint32_t)g.ll_h, lw = (uint32_t)g.ll_w;
-    if (4 * qi + 1 >= h || 8 * t + 1 >= w) return;  // not even q0 has grand-offspring columns / rows
     const size_t base = (size_t)bz * g.hw;
     const int32_t *__restrict__ x = a.x + base;
     uint8_t *__restrict__ dm = a.dmsb + base;
     uint8_t *__restrict__ lm = a.lmsb + base;
-    const uint32_t ci = 2 * qi, cj = 4 * t, gi = 4 * qi, gj = 8 * t;
-    {
-        // Nothing to do here when neither node has depth 2 and none of their offspring has depth 1 (a pair deeper in
-        // the tree: rounds >= 3 take it): leave before the loads -- those offspring and grand-offspring are read by
-        // the threads of THEIR depth, and reading them here as well cost 10 % more traffic than the array holds.
-        bool any = false;
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t r = ci + rr, c = cj + q;
-                any = any || (2 * r + 1 < h && 2 * c + 1 < w && !((uint64_t)4 * r + 1 < h && (uint64_t)4 * c + 1 < w));
-            }
-#pragma unroll
-        for (int pr = 0; pr < 2; pr++) {
-            const uint32_t qj = 2 * t + pr;
-            any = any || ((uint64_t)4 * qj + 1 < w && !((uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w));
-        }
-        if (!any) return;
-    }
-    int32_t xc[2][4], xg[4][8];
-    if (gi + 3 < h && gj + 7 < w) {  // everything in bounds: vector loads, all issued before the first use
-        const i4u c0 = *reinterpret_cast<const i4u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i4u *>(x + (size_t)(ci + 1) * w + cj);
-        i4u r[4][2];
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            r[rr][0] = *reinterpret_cast<const i4u *>(x + (size_t)(gi + rr) * w + gj);
-            r[rr][1] = *reinterpret_cast<const i4u *>(x + (size_t)(gi + rr) * w + gj + 4);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { xc[0][q] = c0.v[q]; xc[1][q] = c1.v[q]; }
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) xg[rr][q] = r[rr][q >> 2].v[q & 3];
-    } else {  // bottom / right edge: element by element, zero outside the array
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) xc[rr][q] = (ci + rr < h && cj + q < w) ? x[(size_t)(ci + rr) * w + cj + q] : 0;
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-            for (int q = 0; q < 8; q++) xg[rr][q] = (gi + rr < h && gj + q < w) ? x[(size_t)(gi + rr) * w + gj + q] : 0;
-    }
-    // children: D of the depth-1 ones
-    uint32_t dch[2][4];
-    bool wr[2][4];
-    bool all_row[2] = {true, true};
+    const uint32_t ci = 2 * qi, cj = 2 * qj, gi = 4 * qi, gj = 4 * qj;
+    const bool dom = 4 * qi + 1 < h && (uint64_t)4 * qj + 1 < w;  // q has grand-offspring rows and columns at all
+    // which of the four offspring have depth exactly 1, and is q of depth exactly 2
+    bool wr[2][2], any = false;
 #pragma unroll
     for (int rr = 0; rr < 2; rr++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 2; q++) {
             const uint32_t r = ci + rr, c = cj + q;
-            const bool has = 2 * r + 1 < h && 2 * c + 1 < w;                   // o has offspring
-            const bool deep = (uint64_t)4 * r + 1 < h && (uint64_t)4 * c + 1 < w;  // ... and grand-offspring: not ours
+            const bool has = 2 * r + 1 < h && 2 * c + 1 < w;
+            const bool deep = (uint64_t)4 * r + 1 < h && (uint64_t)4 * c + 1 < w;
+            wr[rr][q] = dom && has && !deep && !(r < lh && c < lw);
+            any = any || wr[rr][q];
+        }
+    const bool wq = dom && !((uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w) && !(qi < lh && qj < lw);
+    any = any || wq;
+    int32_t xc[2][2] = {{0, 0}, {0, 0}}, xg[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (any) {
+        if (gi + 3 < h && gj + 3 < w) {
+            const i2u c0 = *reinterpret_cast<const i2u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i2u *>(x + (size_t)(ci + 1) * w + cj);
+            i4u r[4];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++) r[rr] = *reinterpret_cast<const i4u *>(x + (size_t)(gi + rr) * w + gj);
+            xc[0][0] = c0.v[0]; xc[0][1] = c0.v[1]; xc[1][0] = c1.v[0]; xc[1][1] = c1.v[1];
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) xg[rr][q] = r[rr].v[q];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) xc[rr][q] = (ci + rr < h && cj + q < w) ? x[(size_t)(ci + rr) * w + cj + q] : 0;
+#pragma unroll
+            for (int rr = 0; rr < 4; rr++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) xg[rr][q] = (gi + rr < h && gj + q < w) ? x[(size_t)(gi + rr) * w + gj + q] : 0;
+        }
+    }
+    uint32_t dch[2][2], dq = 0, lq = 0;
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t r = ci + rr, c = cj + q;
+            const bool has = 2 * r + 1 < h && 2 * c + 1 < w;
             uint32_t d = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) d = max(d, msb_code(iabs_u(xg[2 * rr + (u >> 1)][2 * q + (u & 1)])));
-            dch[rr][q] = has ? d : 0u;  // (for a deeper child this is not D(o); such a q is not finished here either)
-            wr[rr][q] = has && !deep && !(r < lh && c < lw);
-            all_row[rr] = all_row[rr] && wr[rr][q];
+            dch[rr][q] = has ? d : 0u;
+            dq = max(dq, max(msb_code(iabs_u(xc[rr][q])), dch[rr][q]));
+            lq = max(lq, dch[rr][q]);
         }
+    // pack: this lane's bytes | partner's bytes (lanes 2k, 2k+1 own adjacent columns)
+    const uint32_t mine0 = dch[0][0] | (dch[0][1] << 8), mine1 = dch[1][0] | (dch[1][1] << 8);
+    const uint32_t mflags = (wr[0][0] ? 1u : 0u) | (wr[0][1] ? 2u : 0u) | (wr[1][0] ? 4u : 0u) | (wr[1][1] ? 8u : 0u) | (wq ? 16u : 0u);
+    const uint32_t mineq = dq | (lq << 8) | (mflags << 16);
+    const uint32_t oth0 = (uint32_t)__shfl_xor((int)mine0, 1), oth1 = (uint32_t)__shfl_xor((int)mine1, 1);
+    const uint32_t othq = (uint32_t)__shfl_xor((int)mineq, 1);
+    if ((threadIdx.x & 1u) == 0) {
+        const uint32_t oflags = othq >> 16;
+        const uint32_t row[2] = {mine0 | (oth0 << 16), mine1 | (oth1 << 16)};
 #pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        uint8_t *row = dm + (size_t)(ci + rr) * w + cj;
-        if (all_row[rr]) {
-            b4u pk;
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t f4 = ((mflags >> (2 * rr)) & 3u) | (((oflags >> (2 * rr)) & 3u) << 2);
+            uint8_t *p = dm + (size_t)(ci + rr) * w + cj;
+            if (f4 == 15u) {
+                b4u pk;
+                pk.v[0] = (uint8_t)row[rr]; pk.v[1] = (uint8_t)(row[rr] >> 8); pk.v[2] = (uint8_t)(row[rr] >> 16); pk.v[3] = (uint8_t)(row[rr] >> 24);
+                *reinterpret_cast<b4u *>(p) = pk;
+            } else {
 #pragma unroll
-            for (int q = 0; q < 4; q++) pk.v[q] = (uint8_t)dch[rr][q];
-            *reinterpret_cast<b4u *>(row) = pk;
+                for (int q = 0; q < 4; q++)
+                    if ((f4 >> q) & 1u) p[q] = (uint8_t)(row[rr] >> (8 * q));
+            }
+        }
+        const bool w0 = (mflags >> 4) & 1u, w1 = (oflags >> 4) & 1u;
+        const size_t qo = (size_t)qi * w + qj;
+        if (w0 && w1) {
+            b2u pd, pl;
+            pd.v[0] = (uint8_t)dq; pd.v[1] = (uint8_t)othq;
+            pl.v[0] = (uint8_t)lq; pl.v[1] = (uint8_t)(othq >> 8);
+            *reinterpret_cast<b2u *>(dm + qo) = pd;
+            *reinterpret_cast<b2u *>(lm + qo) = pl;
         } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (wr[rr][q]) row[q] = (uint8_t)dch[rr][q];
+            if (w0) { dm[qo] = (uint8_t)dq; lm[qo] = (uint8_t)lq; }
+            if (w1) { dm[qo + 1] = (uint8_t)othq; lm[qo + 1] = (uint8_t)(othq >> 8); }
         }
-    }
-    // the two q nodes: depth exactly 2
-    uint32_t dq[2], lq[2];
-    bool wq[2];
-#pragma unroll
-    for (int pr = 0; pr < 2; pr++) {
-        const uint32_t qj = 2 * t + pr;
-        const bool d2 = (uint64_t)4 * qj + 1 < w;                                      // (4*qi+1 < h holds)
-        const bool d3 = (uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w;
-        uint32_t dd = 0, ll = 0;
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int rr = u >> 1, q = 2 * pr + (u & 1);
-            dd = max(dd, max(msb_code(iabs_u(xc[rr][q])), dch[rr][q]));
-            ll = max(ll, dch[rr][q]);
-        }
-        dq[pr] = dd;
-        lq[pr] = ll;
-        wq[pr] = d2 && !d3 && !(qi < lh && qj < lw);
-    }
-    const size_t qo = (size_t)qi * w + 2 * t;
-    if (wq[0] && wq[1]) {
-        b2u pd, pl;
-        pd.v[0] = (uint8_t)dq[0]; pd.v[1] = (uint8_t)dq[1];
-        pl.v[0] = (uint8_t)lq[0]; pl.v[1] = (uint8_t)lq[1];
-        *reinterpret_cast<b2u *>(dm + qo) = pd;
-        *reinterpret_cast<b2u *>(lm + qo) = pl;
-    } else {
-        if (wq[0]) { dm[qo] = (uint8_t)dq[0]; lm[qo] = (uint8_t)lq[0]; }
-        if (wq[1]) { dm[qo + 1] = (uint8_t)dq[1]; lm[qo + 1] = (uint8_t)lq[1]; }
     }
 }
 
@@ -345,7 +329,8 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
         const uint32_t rows = (uint32_t)(((uint64_t)g->h - 1 + 3) >> 2);   // qi with 4*qi+1 < h
         const uint32_t pairs = (uint32_t)(((uint64_t)g->w - 1 + 7) >> 3);  // t with 8*t+1 < w
         if (rows && pairs) {
-            const uint32_t gx = (pairs + 63) / 64, gy = (rows + 3) / 4, gz = (uint32_t)(B * g->c);
+            const uint32_t cols = 2 * pairs;  // an even number of columns: lane pairs stay together
+            const uint32_t gx = (cols + 63) / 64, gy = (rows + 3) / 4, gz = (uint32_t)(B * g->c);
             hipLaunchKernelGGL(k_pyr_12, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
         }
     }
