@@ -51,6 +51,31 @@ __device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, 
     xcd_tile_at(blockIdx.x, gx, gy, gz, bx, by, bz);
 }
 
+// max |coefficient| of an image, raised by every tile of the image: an atomic on one word, and read-modify-writes of one
+// memory line are served one after the other (11.5 ns each, measured: with one atomic per wavefront a 16-image launch
+// of level 1 took 1.6 ms for its 141 000 atomics, six times what its bytes take, and 256 images were as much
+// atomic-bound as HBM-bound).  So: one atomic per workgroup (the wavefronts meet in an LDS word first), and none when
+// the word already holds as much (MAXLOOK: 0 no look, 1 a cached load, 2 a load the atomics' coherence point answers;
+// a stale answer only costs a spare atomic).  `s_m` must have been zeroed before an earlier barrier.
+#ifndef MAXLOOK
+#define MAXLOOK 1
+#endif
+__device__ __forceinline__ void block_raise_max(uint32_t *p, uint32_t v, uint32_t *s_m) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+    if ((threadIdx.x & 63) == 0 && v) atomicMax(s_m, v);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = *s_m;
+#if MAXLOOK == 0
+        if (m) atomicMax(p, m);
+#elif MAXLOOK == 1
+        if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(p, m);
+#else
+        if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, m);
+#endif
+    }
+}
+
 __device__ __forceinline__ int ext_index(int i, int N, int mode) {
     if (i >= 0 && i < N) return i;
     switch (mode) {
@@ -101,6 +126,8 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     // input row needed for output row o, tap j: 2*o + 1 - j ; first needed row r0 = 2*oh0 + 1 - (F-1)
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
     if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
+    __shared__ uint32_t s_amax;
+    if (tid == 0) s_amax = 0;
     __syncthreads();
 
     // ---- axis -2: thread <-> input column; all loads first, then the filter ----
@@ -167,8 +194,7 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
         if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 
@@ -200,6 +226,8 @@ template <int F>
 __global__ __launch_bounds__(256) void k_dwt_edge(DwtKArgs a) {
     __shared__ double s_f[2][F];  // taps, indexed at run time below
     if (threadIdx.x < F) { s_f[0][threadIdx.x] = a.lo[threadIdx.x]; s_f[1][threadIdx.x] = a.hi[threadIdx.x]; }
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0;
     __syncthreads();
     const int nr = a.out_h - a.ov_h, nc = a.out_w - a.ov_w;        // overhang rows / columns
     const int nA = nr * a.out_w, total = nA + a.ov_h * nc;          // all columns of those rows + the rest of those columns
@@ -259,8 +287,7 @@ __global__ __launch_bounds__(256) void k_dwt_edge(DwtKArgs a) {
         amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((threadIdx.x & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 
@@ -300,6 +327,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
     if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
     if (tid < F) { s_flo[tid] = (float)a.lo[tid]; s_fhi[tid] = (float)a.hi[tid]; }
+    __shared__ uint32_t s_amax;
+    if (tid == 0) s_amax = 0;
     __syncthreads();
 
     // ---- axis -2 ----
@@ -387,8 +416,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
         amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
     if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 
@@ -407,6 +435,8 @@ __global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint
     constexpr int HC = 128 + 2;
     __shared__ double s_lo[2][2][HC];        // [step parity][column parity][column >> 1]
     __shared__ double s_hi[2][2][HC];
+    __shared__ uint32_t s_amax;
+    if (threadIdx.x == 0) s_amax = 0;  // (the barriers of the row loop come before its use)
     uint32_t tbx, tby, tbz;
     xcd_tile(gx, gy, a.planes, tbx, tby, tbz);
     const int plane = (int)tbz;
@@ -490,8 +520,7 @@ __global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint
         }
     }
     if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 #endif  // SPIHT_DIAG
@@ -583,7 +612,9 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
     __shared__ double s_lo[2][3][2][HC];     // [output row parity][channel][column parity][column >> 1]
     __shared__ double s_hi[2][3][2][HC];
     __shared__ SpowLds s_pw;
+    __shared__ uint32_t s_amax;
     spow_lds_fill(s_pw, threadIdx.x);
+    if (threadIdx.x == 0) s_amax = 0;
     __syncthreads();
     uint32_t tbx, tby, tbz;
     xcd_tile(gx, gy, a.planes / 3, tbx, tby, tbz);
@@ -722,8 +753,7 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
         }
     }
     if (a.maxabs != nullptr) {
-        for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-        if ((tid & 63) == 0 && amax) atomicMax(&a.maxabs[img], amax);
+        block_raise_max(&a.maxabs[img], amax, &s_amax);
     }
 }
 
