@@ -28,7 +28,7 @@ int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nby
 int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
                         hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
-int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st);
+int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
                              double q, uint32_t *maxabs, hipStream_t st);
 int spiht_launch_zero_pads(int L, const int64_t *hs, const int64_t *ws, const int64_t *offh, const int64_t *offw, int enc_h,
@@ -82,6 +82,8 @@ struct spiht_ctx {
     // grow-only scratch
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
+    DevBuf tilebuf;      // tile counters of the persistent inverse-transform kernel
+    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
@@ -369,6 +371,10 @@ extern "C" int spiht_ctx_create_priority(int device, int priority, spiht_ctx **o
     int rc = ensure(ctx, ctx->err, 256);
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
     (void)hipMemset(ctx->err.p, 0, 256);
+    rc = ensure(ctx, ctx->tilebuf, 8 * 32 * sizeof(uint32_t));
+    if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
+    (void)hipMemset(ctx->tilebuf.p, 0, 8 * 32 * sizeof(uint32_t));
+    ctx->tilectr.dev = (uint32_t *)ctx->tilebuf.p;
     *out = ctx;
     return SPIHT_OK;
 }
@@ -379,7 +385,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
-                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec};
+                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -1031,7 +1037,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
         {
             StageTimer t(ctx, l == 1 ? ST_IDWT_L1 : ST_IDWT_REST);
-            LAUNCHCHK(spiht_launch_idwt_level(&a, planes, ctx->stream));
+            LAUNCHCHK(spiht_launch_idwt_level(&a, planes, ctx->stream, ctx->tilectr.dev ? &ctx->tilectr : nullptr));
         }
         a_in = a.out;
         ah = a.out_h;

@@ -155,6 +155,15 @@ struct DwtKArgs {
 };
 
 // One inverse DWT level (dwt.hip)
+// Tile hand-out of the persistent inverse-transform kernel (k_idwt_level_pf): one counter per XCD in device memory,
+// never reset -- the launcher knows how many numbers a launch draws from each (tiles + 2 per workgroup) and hands the
+// kernel the counter values it starts from (all arithmetic modulo 2^32).
+struct TileCtr {
+    uint32_t *dev;      // 8 counters, 32 words apart (a memory line each); zero when allocated
+    uint32_t base[8];   // host-side: value of each counter before the next launch
+};
+struct TileBase { uint32_t v[8]; };
+
 struct IdwtKArgs {
     int32_t c;
     int32_t F;

@@ -802,8 +802,10 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // inverse
 // ------------------------------------------------------------------------------------------------
 #ifndef IW_TH
-#define IW_TH 16    // output rows per tile (two halves of 8, one per half of the workgroup; a multiple of 4).  Level 1 of 256
-#endif              // 1080p images: 16 rows 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67, 8: 4.74
+#define IW_TH 24    // output rows per tile (two halves, one per half of the workgroup; a multiple of 4).  Level 1 of 256
+#endif              // 1080p images, workgroup per tile: 16 rows 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67,
+                    // 8: 4.74; persistent kernel beside the list decoder (the pipelined schedule): 16 rows 7.3 ms, 20: 7.0,
+                    // 24: 6.5-6.7, 28: 8.1, 32: 7.6
 #define IW_TW 128   // output cols per tile, one thread per column per half
 
 __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
@@ -941,11 +943,23 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 #ifndef IWP_WG
 #define IWP_WG 4
 #endif
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+#ifndef IWP_PEEL
+#define IWP_PEEL 1
+#endif
+#ifndef IWP_USTORE
+#define IWP_USTORE 1
+#endif
+#ifdef IWP_WAVES  // experiment: cap the kernel's registers at what IWP_WAVES wavefronts per SIMD leave each
+#define IWP_ATTR __attribute__((amdgpu_waves_per_eu(IWP_WAVES, IWP_WAVES)))
+#else
 #define IWP_ATTR
+#endif
 template <int F, uint32_t LOM, uint32_t HIM, bool FIRST>  // FIRST: coarsest level, the approximation comes from the packed array
-__global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy) {
+__global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr,
+                                                                      TileBase cb) {
     constexpr int HF = F / 2;
     constexpr int KH = IW_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IW_TH / 4 + HF - 1;
     constexpr int NE = (KH * KW + DW_BLOCK - 1) / DW_BLOCK;  // staged elements per thread
@@ -957,11 +971,33 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     const uint32_t x = blockIdx.x & 7u, q = nt >> 3, r8 = nt & 7u;
     const uint32_t base = x * q + (x < r8 ? x : r8), cnt = q + (x < r8 ? 1u : 0u);
     const uint32_t per = (G + 7u - x) >> 3;  // workgroups of this launch on XCD x
-    uint32_t k = blockIdx.x >> 3;            // position of the next tile in the XCD's range
+    // Which tile next: with a fixed stride (tile k, k + per, ...) the workgroups drift apart over a few hundred tiles,
+    // the tiles in flight on an XCD stop being neighbours and the halo rows two tiles share are fetched from HBM twice
+    // (PMC: 40 instead of 31.6 MB read per 1080p image).  So the XCD's workgroups draw their tiles from a counter: what
+    // is in flight is always one contiguous window of the range, as with one workgroup per tile.  Thread 0 draws a
+    // tile two ahead (the answer travels under a whole tile of work) and passes it on through s_next.
+    __shared__ uint32_t s_next[2];
+    uint32_t *const myctr = ctr ? ctr + 32u * x : nullptr;
+    const uint32_t cbase = cb.v[x];
+    uint32_t k, kn;  // position in the XCD's range of the tile being worked on / of the one after
+    if (myctr) {
+        if (tid == 0) {
+            s_next[0] = atomicAdd(myctr, 1u) - cbase;
+            s_next[1] = atomicAdd(myctr, 1u) - cbase;
+        }
+        __syncthreads();
+        k = __builtin_amdgcn_readfirstlane(s_next[0]);  // (workgroup-uniform; said so, the tile arithmetic stays scalar)
+        kn = __builtin_amdgcn_readfirstlane(s_next[1]);
+        __syncthreads();
+    } else {
+        k = blockIdx.x >> 3;
+        kn = k + per;
+    }
 
     struct Stage {  // the samples of one tile on their way from memory: 15 registers per thread
         int32_t rad[NE], rda[NE], rdd[NE], raa[NE];
         double vaa[NE];
+        double mk;  // the plane's channel scale (a load as well: it must not be waited for on its own)
     };
     auto request = [&](Stage &g, uint32_t T) {  // the loads of tile T (nothing waits for them here)
         const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
@@ -981,6 +1017,7 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
             if (FIRST) { g.raa[e] = rec[(size_t)bi * a.enc_w + bj]; g.vaa[e] = 0.0; }
             else { g.vaa[e] = ain[(size_t)bi * a.a_w + bj]; g.raa[e] = 0; }
         }
+        g.mk = a.mults != nullptr ? a.mults[plane % (uint32_t)a.c] : 1.0;
     };
     // taps of axis -1 for this thread's column parity (n0 is even: the parity is the same in every tile)
     const int nn = tid & (IW_TW - 1), half = tid / IW_TW, np = nn & 1, cl = nn / 2;
@@ -992,11 +1029,11 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     }
     const bool has_m = a.mults != nullptr;
     // one tile: its samples (in g) -> LDS, then g is free and takes the loads of the next tile; filter; store
-    auto tile = [&](Stage &g, uint32_t kk) {
+    auto tile = [&](Stage &g, uint32_t kk, uint32_t knext) {
         const uint32_t T = base + kk;
         const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
         const int kh0s = (int)(by * IW_TH) / 2, kw0s = (int)(bx * IW_TW) / 2;
-        const double mk = has_m ? a.mults[plane % (uint32_t)a.c] : 1.0;
+        const double mk = g.mk;
         const bool zero_ok = (!has_m || mk > 0.0) && a.q > 0.0;  // 0/m/q == +0.0 exactly: skip the divisions
 #pragma unroll
         for (int e = 0; e < NE; e++) {
@@ -1011,16 +1048,31 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
                 s_b[3][rr][cidx] = (!in || (g.rdd[e] == 0 && zero_ok)) ? 0.0 : dequant(g.rdd[e], mk, a.q, has_m);
             }
         }
-        if (kk + per < cnt) request(g, base + kk + per);
-        lds_barrier();
+        // the tile after `knext` is drawn here -- behind the wait for this tile's samples, ahead of the next tile's
+        // loads -- and looked at only at the end of the tile (raw: a subtraction here would wait for the answer)
+        uint32_t drawn = 0;
+        if (myctr && tid == 0) drawn = atomicAdd(myctr, 1u);
+        request(g, base + min(knext, cnt - 1u));  // unconditional (past the end: the last tile again, never used): a
+        lds_barrier();                            // branch around loads makes every later wait a wait for all of them
         // ---- thread = (output column nn, half): as k_idwt_level ----
         const int m0 = (int)by * IW_TH, n0 = (int)bx * IW_TW, kh0 = m0 / 2;
         const int n = n0 + nn;
         double wl[HF], wh[HF];
 #pragma unroll
         for (int s2 = 0; s2 < HF; s2++) { wl[s2] = 0.0; wh[s2] = 0.0; }
-        double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
         const int rbase = half * (IW_TH / 4);
+#if IWP_USTORE
+        // Stores through a buffer descriptor of the plane: what falls outside the picture (rows past the plane's end by
+        // the descriptor's range check, columns past out_w by an offset beyond it) is dropped by the hardware, so the
+        // stores stand in straight-line code.  With branches around them the compiler cannot count them, and the wait
+        // for the next tile's samples at the top of the loop becomes a wait for these stores as well.
+        const uint32_t row_bytes = (uint32_t)a.out_w * 8u;
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            a.out + (size_t)plane * a.out_h * a.out_w, 0, (int)((uint32_t)a.out_h * row_bytes), 0x00020000);
+        const uint32_t voff0 = n < a.out_w ? (uint32_t)(2 * (kh0 + rbase)) * row_bytes + (uint32_t)n * 8u : 0x80000000u;
+#else
+        double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
+#endif
 #pragma unroll
         for (int rr = 0; rr < KHH; rr++) {
             const int r = rbase + rr;
@@ -1045,7 +1097,9 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
             wl[HF - 1] = tl;
             wh[HF - 1] = th;
             if (rr >= HF - 1) {
+#if !IWP_USTORE
                 const int m = 2 * (kh0 + r - (HF - 1));
+#endif
 #pragma unroll
                 for (int mp = 0; mp < 2; mp++) {
                     double sa = 0.0, sd = 0.0;
@@ -1057,17 +1111,37 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
                         if (hnz) sd += wh[s2] * a.hi[mp + F - 2 - 2 * s2];
                     }
                     const double sacc = (0.0 + sa) + sd;
+#if IWP_USTORE
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sacc), orsrc,
+                                                          voff0 + (uint32_t)(2 * (rr - (HF - 1)) + mp) * row_bytes, 0, 0);
+#else
                     if (m + mp < a.out_h && n < a.out_w) out[(size_t)(m + mp) * a.out_w + n] = sacc;
+#endif
                 }
             }
         }
+        if (myctr && tid == 0) s_next[0] = drawn - cbase;
         lds_barrier();  // every wave has read the tile before the next one is written over it
     };
     // One tile ahead.  (Two ahead -- a second register set, 116 VGPRs -- leaves room for ONE such workgroup per CU beside
     // a decoder instead of two and was slower there: 9.2-10.6 instead of 7.2 ms for level 1.)
     Stage g0;
-    if (k < cnt) request(g0, base + k);
-    for (; k < cnt; k += per) tile(g0, k);
+    if (k >= cnt) return;
+    request(g0, base + k);
+    // The first tile stands outside the loop: inside it the wait for a tile's samples can then be "all but the stores
+    // issued since" on every path into the loop head (with the first trip inside, nothing follows the samples' loads on
+    // the path from above, and the compiler has to make it a wait for everything -- the stores of the tile before).
+#if IWP_PEEL
+    tile(g0, k, kn);
+    k = kn;
+    kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;  // (s_next[0] is written again only behind the
+                                                                         // next tile's first barrier)
+#endif
+    while (k < cnt) {
+        tile(g0, k, kn);
+        k = kn;
+        kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;
+    }
 }
 
 // ---- level 1 of the inverse transform of a 3-channel image with the colour model change on its stores ------------
@@ -1246,7 +1320,7 @@ static int launch_dwt_F(const DwtKArgs &a, int planes, hipStream_t st) {
     return launch_dwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st);
 }
 template <int F, uint32_t LOM, uint32_t HIM>
-static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st) {
+static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) {
     a.planes = planes;
     if (a.color) {  // level 1 of a 3-channel image, colour model change on the stores
         uint32_t ntc = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW) * (uint32_t)((a.out_h + IWC_TH - 1) / IWC_TH) * (uint32_t)(planes / 3);
@@ -1264,24 +1338,32 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st) {
     }();
     // a level with several tiles per workgroup slot: persistent workgroups that fetch a tile ahead
     static const uint32_t pf_min = [] { const char *e = getenv("SPIHT_IDWT_PF_MIN"); return e ? (uint32_t)atol(e) : 20000u; }();
-    if (pf && nt >= pf_min) {
+    if (pf && tc && nt >= pf_min && (uint64_t)(a.out_h + IW_TH) * a.out_w * 8u < (1ull << 31)) {
         const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : IWP_WG));
-        if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy);
-        else hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy);
+        static const int dyn = [] { const char *e = getenv("SPIHT_IDWT_DYN"); return e ? atoi(e) : 1; }();
+        TileBase cb;
+        uint32_t *ctr = (tc && dyn) ? tc->dev : nullptr;
+        for (uint32_t x = 0; x < 8; x++) {
+            cb.v[x] = ctr ? tc->base[x] : 0u;
+            // XCD x draws one number per tile of its range and two more per workgroup (the look-ahead past the end)
+            if (ctr) tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
+        }
+        if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
+        else hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
         return (int)hipGetLastError();
     }
     hipLaunchKernelGGL((k_idwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
 }
 template <int F, uint32_t LOM, uint32_t HIM>
-static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st) {
+static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st, TileCtr *tc) {
     uint32_t lom = 0, him = 0;
     for (int j = 0; j < F; j++) {
         if (a.lo[j] != 0.0) lom |= 1u << j;
         if (a.hi[j] != 0.0) him |= 1u << j;
     }
-    if (lom == LOM && him == HIM) return launch_idwt_FM<F, LOM, HIM>(a, planes, st);
-    return launch_idwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st);
+    if (lom == LOM && him == HIM) return launch_idwt_FM<F, LOM, HIM>(a, planes, st, tc);
+    return launch_idwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st, tc);
 }
 
 extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st) {
@@ -1293,12 +1375,13 @@ extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t
     default: return -1;
     }
 }
-extern "C" int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st) {
+// tc: tile counters of the calling context (nullptr: fixed-stride tile order in the persistent kernel)
+extern "C" int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc) {
     switch (a->F) {
-    case 2: return launch_idwt_F<2, 0x3u, 0x3u>(*a, planes, st);            // haar
-    case 6: return launch_idwt_F<6, 0x0Eu, 0x3Eu>(*a, planes, st);          // bior2.2 rec_lo / rec_hi
-    case 10: return launch_idwt_F<10, 0x0FEu, 0x3FEu>(*a, planes, st);      // bior4.4
-    case 18: return launch_idwt_F<18, 0x3FF8u, 0x3FFFEu>(*a, planes, st);   // bior6.8
+    case 2: return launch_idwt_F<2, 0x3u, 0x3u>(*a, planes, st, tc);            // haar
+    case 6: return launch_idwt_F<6, 0x0Eu, 0x3Eu>(*a, planes, st, tc);          // bior2.2 rec_lo / rec_hi
+    case 10: return launch_idwt_F<10, 0x0FEu, 0x3FEu>(*a, planes, st, tc);      // bior4.4
+    case 18: return launch_idwt_F<18, 0x3FF8u, 0x3FFFEu>(*a, planes, st, tc);   // bior6.8
     default: return -1;
     }
 }

@@ -34,7 +34,8 @@ def counters(stage, kernel):
             for r in csv.DictReader(open(p)):
                 if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
                     by.setdefault((r["Kernel_Name"], int(r["Grid_Size"])), []).append(float(r["Counter_Value"]))
-        res[counter] = {g: sum(v) / len(v) for g, v in by.items()}
+        # persistent kernels have one grid size for every level they run: the ITERS largest values are level 1's
+        res[counter] = {g: sum(sorted(v)[-ITERS:]) / min(len(v), ITERS) for g, v in by.items()}
     return res
 
 

@@ -20,12 +20,16 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     subprocess.check_call(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                            "python3", os.path.join(ROOT, "tools", "prof_stage.py"), stage, str(B), "2"],
                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    vals = {}
+    vals, names = {}, {}
     for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(p)):
             if ksub in r["Kernel_Name"] and r["Counter_Name"] == counter:
                 vals.setdefault(r["Dispatch_Id"], 0.0)
                 vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
+                names[r["Dispatch_Id"]] = "%s grid %s" % (r["Kernel_Name"][:48], r["Grid_Size"])
+    if os.environ.get("KT_LIST"):  # every launch on its own (a persistent kernel has one grid size for all levels)
+        for k in sorted(vals, key=int):
+            print("  %-10s %-70s %12.0f KiB" % (counter, names[k], vals[k]), file=sys.stderr)
     out[counter + "_KiB_per_launch"] = sum(vals.values()) / max(len(vals), 1)
     out["launches"] = len(vals)
 out["read_bytes_per_image"] = out["FETCH_SIZE_KiB_per_launch"] * 1024 * 2 / B
