@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--l-priority", type=int, default=0, help="experiment: stream priority of the list-coding contexts")
     ap.add_argument("--e-first", type=int, default=0, help="experiment: encoder kernel queued before the unscatter")
     ap.add_argument("--u-early", type=int, default=0, help="experiment: unscatter right behind the inverse transform")
+    ap.add_argument("--decoder-waves", type=int, default=8, choices=[8, 12],
+                    help="wavefronts per decoder workgroup in the pipelined schedule (12: the library's default for single calls)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -273,7 +275,7 @@ def main():
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
         from spiht_amd.batch import OverlappedCodec
         pipe = OverlappedCodec(codec, B, pair=args.pair, split_inverse=bool(args.split_inverse), l_priority=args.l_priority,
-                               e_first=bool(args.e_first), u_early=bool(args.u_early))
+                               e_first=bool(args.e_first), u_early=bool(args.u_early), decoder_waves=args.decoder_waves)
         ctxs.extend(pipe.Ls)
 
     def step():
@@ -499,6 +501,7 @@ def main():
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
                        "images_per_gpu": B, "distinct_images_per_gpu": nd, "seeds": "1000 + global image index",
                        "streams": K, "images_per_launch": per_launch,
+                       "decoder_waves": args.decoder_waves if pipe is not None else 12,
                        "schedule": ("steps software-pipelined: HBM-bound passes of steps i+1 / i-1 on one stream while step i is "
                                     "list-coded on another" if pipe is not None else "stages back to back"),
                        "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),

@@ -249,6 +249,12 @@ int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, in
 int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const double *M_f, double p_f, const double *A_i,
                          const double *M_i, double p_i);
 
+/* Wavefronts per workgroup of the list decoder on this context: 12 (default; the shortest walk of one stream) or 8
+ * (4 % slower alone, a lighter neighbour for HBM-bound kernels running beside it on other contexts -- what the
+ * pipelined schedule uses for its list-coding contexts).  Output identical.  Other values: SPIHT_ERR_ARG.
+ * Replaces nothing in the reference (src/encoder_decoder.rs:307-454 is one thread); a scheduling knob of this library. */
+int spiht_ctx_set_decoder_waves(spiht_ctx *ctx, int waves);
+
 /* d_nbytes[b] = ceil(d_nbits[b] / 8) for b < B (device arrays): turns the encoder's bit counts into the byte
  * counts the decoder takes, without a host round trip. */
 int spiht_nbits_to_nbytes(spiht_ctx *ctx, const uint64_t *d_nbits, int64_t B, uint64_t *d_nbytes);

@@ -191,7 +191,8 @@ class OverlappedCodec:
     `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
-    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=False):
+    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=False,
+                 decoder_waves=8):
         self.codec, self.B = codec, int(B)
         if pair not in ("forward", "inverse"):
             raise ValueError("pair must be 'forward' or 'inverse'")
@@ -199,6 +200,10 @@ class OverlappedCodec:
         self.H = codec.ctx
         self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device, l_priority),
                    _lib.Context(self.H.device, l_priority)]
+        # decoder workgroups of 8 instead of 12 wavefronts: a longer walk (11.4 instead of 8.9 ms per 256 1080p streams
+        # in this schedule), but the transforms beside it lose less, and they are the longer queue
+        for cx in self.Ls:
+            cx.set_decoder_waves(decoder_waves)
         self.e_first = bool(e_first)  # experiment: encoder kernel queued before the unscatter
         self.u_early = bool(u_early)  # the unscatter of a batch right behind its inverse transform (off the next list-coding chain)
         self._unscattered = [True, True]

@@ -20,6 +20,7 @@ int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxab
 int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
+int spiht_launch_decode_w8(const DecArgs *a, hipStream_t st);  // the 8-wavefront build of decode.hip
 int spiht_launch_unscatter(const DecArgs *a, hipStream_t st);
 int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes);
 int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
@@ -89,6 +90,7 @@ struct spiht_ctx {
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
     bool color_on = false;
     Color3 col_fwd, col_inv;
+    int dec_waves = 12;  // wavefronts per decoder workgroup (spiht_ctx_set_decoder_waves)
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -606,7 +608,7 @@ static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, u
     }
     {
         StageTimer t(ctx, ST_DEC_LISTS);
-        LAUNCHCHK(spiht_launch_decode(&a, ctx->stream));
+        LAUNCHCHK(ctx->dec_waves == 8 ? spiht_launch_decode_w8(&a, ctx->stream) : spiht_launch_decode(&a, ctx->stream));
     }
     if (args_out) *args_out = a;
     return SPIHT_OK;
@@ -1489,6 +1491,16 @@ extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, i
     } else {
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)B * (size_t)(c * h * w) * 4, ctx->stream));
     }
+    return SPIHT_OK;
+}
+
+// Width of the list decoder's workgroups on this context.  12 wavefronts (default) walk one stream fastest; 8 take 4 %
+// longer alone but leave the HBM-bound kernels that share the CUs with the decoder more room -- the setting of the
+// list-coding contexts of the pipelined schedule (spiht_amd/batch.py: OverlappedCodec).  Same output either way.
+extern "C" int spiht_ctx_set_decoder_waves(spiht_ctx *ctx, int waves) {
+    if (!ctx || (waves != 8 && waves != 12)) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    ctx->dec_waves = waves;
     return SPIHT_OK;
 }
 

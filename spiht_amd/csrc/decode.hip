@@ -54,6 +54,21 @@ static_assert((DEC_RING & (DEC_RING - 1)) == 0 && DEC_RING <= DEC_NW * 64, "ring
 #define PF_CNT(k, v)
 #endif
 
+// Two builds of this file are linked (Makefile): 12 wavefronts per workgroup -- the shortest walk of one stream -- and
+// 8 (-DDEC_NW=8 -DDEC_VARIANT=w8): slower alone (8.3 instead of 8.0 ms per 256 images), but a lighter neighbour for the
+// HBM-bound kernels the pipelined schedule runs beside it (spiht_ctx_set_decoder_waves).  Everything below lives in a
+// namespace of the build so that the kernels of the two differ in name.
+#ifdef DEC_VARIANT
+#define DEC_CAT2(a, b) a##b
+#define DEC_CAT(a, b) DEC_CAT2(a, b)
+#define DEC_NS DEC_CAT(dec_, DEC_VARIANT)
+#define DEC_LAUNCH DEC_CAT(spiht_launch_decode_, DEC_VARIANT)
+#else
+#define DEC_NS dec_main
+#define DEC_LAUNCH spiht_launch_decode
+#endif
+namespace DEC_NS {
+
 struct Item {  // one 64-bit stream window of one pass
     uint32_t kind;        // 0 = LIP window, 1 = LIS window
     uint32_t Wb;          // stream position of window bit 0
@@ -1301,6 +1316,9 @@ void k_decode(DecArgs a) {
     }
 }
 
+}  // namespace DEC_NS
+
+#ifndef DEC_VARIANT
 // Puts back the zeros: clears exactly the cells the decoder wrote (its LSP lists are still in the slot scratch), so a
 // coefficient array that is only ever used as decoder output and inverse-transform input never needs a full zero-fill
 // again.  One image per slot (B <= nslots).
@@ -1333,12 +1351,14 @@ extern "C" int spiht_launch_unscatter(const DecArgs *a, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-extern "C" int spiht_launch_decode(const DecArgs *a, hipStream_t st) {
+#endif  // !DEC_VARIANT
+
+extern "C" int DEC_LAUNCH(const DecArgs *a, hipStream_t st) {
     int grid = a->nslots < a->B ? a->nslots : a->B;
     if (grid < 1) return 0;
     if (a->tr_ent)
-        hipLaunchKernelGGL(k_decode<true>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
+        hipLaunchKernelGGL(DEC_NS::k_decode<true>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
     else
-        hipLaunchKernelGGL(k_decode<false>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
+        hipLaunchKernelGGL(DEC_NS::k_decode<false>, dim3(grid), dim3(DEC_NW * 64), 0, st, *a);
     return (int)hipGetLastError();
 }

@@ -142,6 +142,39 @@ def test_decode_arbitrary_bytes(oracle):
             _check_decode(oracle, d, 6, (c, h, w), lh, lw)
 
 
+def test_decoder_with_eight_wavefronts(oracle):
+    """The 8-wavefront build of the decoder (spiht_ctx_set_decoder_waves: the list-coding contexts of the pipelined
+    schedule use it) decodes what the 12-wavefront one does: encoder streams, their prefixes, arbitrary bytes on trees
+    with duplicated nodes, and the metadata rows."""
+    import spiht_amd
+    from spiht_amd import _lib
+    ctx = _lib.default_context()
+    with pytest.raises(ValueError):
+        ctx.set_decoder_waves(10)
+    ctx.set_decoder_waves(8)
+    try:
+        rng = np.random.default_rng(23)
+        for (c, h, w, lh, lw) in [(1, 16, 16, 2, 2), (3, 13, 17, 3, 5), (2, 26, 38, 13, 19), (3, 293, 501, 13, 19), (1, 533, 533, 20, 20)]:
+            x = synth_coeffs(7, c, h, w, lh, lw)
+            d, n = oracle.encode(x, lh, lw, min(200000, 8 * c * h * w))
+            for cut in (len(d), len(d) // 2, 7, 1):
+                _check_decode(oracle, d[:cut], n, (c, h, w), lh, lw)
+            for ln in (3, 200, 1500):
+                _check_decode(oracle, rng.integers(0, 256, ln, dtype=np.uint8).tobytes(), 6, (c, h, w), lh, lw)
+        c, h, w, lh, lw = 3, 40, 56, 5, 7
+        x = synth_coeffs(9, c, h, w, lh, lw)
+        d, n = oracle.encode(x, lh, lw, 6000)
+        top = [(0, lh), (0, lw)]
+        other = [[[(lh, 2 * lh), (0, lw)], [(0, lh), (lw, 2 * lw)], [(lh, 2 * lh), (lw, 2 * lw)]],
+                 [[(2 * lh, 4 * lh), (0, 2 * lw)], [(0, 2 * lh), (2 * lw, 4 * lw)], [(2 * lh, 4 * lh), (2 * lw, 4 * lw)]],
+                 [[(4 * lh, 8 * lh), (0, 4 * lw)], [(0, 4 * lh), (4 * lw, 8 * lw)], [(4 * lh, 8 * lh), (4 * lw, 8 * lw)]]]
+        rec, meta = spiht_amd.spiht.decode_with_metadata(d, n, c, h, w, lh, lw, top, other)
+        rec_o, meta_o = oracle.decode_with_metadata(d, n, c, h, w, lh, lw, top, other)
+        assert np.array_equal(rec, rec_o) and np.array_equal(meta, meta_o)
+    finally:
+        ctx.set_decoder_waves(12)
+
+
 def test_decode_bit_flipped_stream_odd_ll(oracle):
     """A damaged encoder stream on the geometry class of BASELINE config 2 (ll 13x19, both odd): after the first flipped
     bit the decoder walks a different path than the encoder did and the duplicated cells' list entries diverge."""
