@@ -68,7 +68,9 @@ json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dwt_l1_traffic.json"), "w"
 print(json.dumps(out))
 # inverse level 1 (largest grid of k_idwt_level) and the pyramid (all rounds of k_pyr_round + k_pyr_ll are small)
 other = {"images_per_launch": B}
-c = counters("idwt", "k_idwt_level")
+c = counters("idwt", "k_idwt_level_pf")  # the persistent kernel takes the large levels (one grid size: see counters())
+if not c["FETCH_SIZE"]:
+    c = counters("idwt", "k_idwt_level")
 rd, wr = bytes_of(c, level1(c))
 other["idwt_level1"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
                         "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
