@@ -28,8 +28,7 @@ int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_i
 int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st);
 int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
                         hipStream_t st);
-int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
-uint32_t spiht_dwt_level_tiles(int out_h, int out_w, int planes);
+int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
                              double q, uint32_t *maxabs, hipStream_t st);
@@ -84,8 +83,8 @@ struct spiht_ctx {
     // grow-only scratch
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
-    DevBuf tilebuf, tmaxbuf;  // tile counters / per-tile maxima of the persistent transform kernels
-    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, nullptr, 0};
+    DevBuf tilebuf;      // tile counters of the persistent inverse-transform kernel
+    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
@@ -388,7 +387,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
-                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf, &ctx->tmaxbuf};
+                      &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     for (auto &r : ctx->pending) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -954,12 +953,6 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         LAUNCHCHK(spiht_launch_zero_pads(ig.L, ig.hs, ig.ws, ig.offh, ig.offw, (int)ig.enc_h, (int)ig.enc_w, d_coeffs, planes,
                                          ctx->stream));
     }
-    if (d_maxabs && !f32) {  // per-tile maxima of the persistent level kernel (level 1 has the most tiles)
-        const uint32_t nt1 = spiht_dwt_level_tiles((int)ig.hs[1], (int)ig.ws[1], planes);
-        CHK(ensure(ctx, ctx->tmaxbuf, (size_t)nt1 * 4));
-        ctx->tilectr.tmax = (uint32_t *)ctx->tmaxbuf.p;
-        ctx->tilectr.tmax_cap = (uint32_t)(ctx->tmaxbuf.cap / 4);
-    }
     if (ig.L >= 2) {
         CHK(ensure(ctx, ctx->a0, (size_t)planes * ig.hs[1] * ig.ws[1] * 8));
         if (ig.L >= 3) CHK(ensure(ctx, ctx->a1, (size_t)planes * ig.hs[2] * ig.ws[2] * 8));
@@ -988,7 +981,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
         {
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
-            LAUNCHCHK(spiht_launch_dwt_level(&a, planes, ctx->stream, ctx->tilectr.dev ? &ctx->tilectr : nullptr));
+            LAUNCHCHK(spiht_launch_dwt_level(&a, planes, ctx->stream));
         }
         in = a.ll_out;
     }

@@ -161,8 +161,6 @@ struct DwtKArgs {
 struct TileCtr {
     uint32_t *dev;      // 8 counters, 32 words apart (a memory line each); zero when allocated
     uint32_t base[8];   // host-side: value of each counter before the next launch
-    uint32_t *tmax;     // scratch of the persistent forward kernel: max |coefficient| per tile (folded into the per-image
-    uint32_t tmax_cap;  //   maxima by k_tmax_fold); capacity in words, 0: none
 };
 struct TileBase { uint32_t v[8]; };
 

@@ -212,27 +212,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     dwt_tile<F, LOM, HIM, PS, NR>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
 }
 
-// ---- the forward level as persistent workgroups that fetch one tile ahead -------------------------------------------------
-// k_dwt_level is a workgroup per tile: request the tile's input rows, wait a memory latency, filter, store, exit -- the
-// latency is covered by the other workgroups of the CU, and beside a list decoder (the pipelined schedule of
-// spiht_amd/batch.py) there are too few of them: level 1 of 256 1080p images takes 5.9 instead of 4.0 ms there.  Here a
-// workgroup walks a sequence of tiles; the samples of tile k+1 are requested (into the registers the column filter of
-// tile k has just emptied) before the row filter of tile k runs, so their latency passes under that work.
-//   * Tile: DW_TH output rows x PW_TW = (130 - F) / 2 output columns, i.e. exactly 128 input columns, and a thread is
-//     (input column, half): the two halves of the workgroup take the upper and the lower DW_TH / 2 output rows, each
-//     thread holds the DW_TH + F - 2 input rows its half needs (16 float64 for bior2.2, where a thread per column
-//     alone would hold 28 and half the workgroup would idle through the column filter).
-//   * Everything a wait could trip over stands in straight-line code the compiler can count: loads and stores go through
-//     buffer descriptors of the plane (what lies outside -- extension mode "zero", outputs beyond the band -- is an
-//     offset past the descriptor's range: loads return 0, stores are dropped), the barriers are bare s_barrier behind
-//     an lgkmcnt wait, and the tile's max |coefficient| goes to a per-tile word (k_tmax_fold adds the words up per
-//     image afterwards) instead of an atomic under a branch.
-//   * Tiles are drawn from a per-XCD counter as in k_idwt_level_pf (see there).
-// Same arithmetic in the same order as dwt_tile: bit-identical output.
-#ifndef DWP_WG
-#define DWP_WG 4  // workgroups per CU at most
-#endif
+// ---- helpers of the persistent inverse-transform kernel (k_idwt_level_pf) -------------------------------------------
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// a barrier that waits for LDS traffic only: __syncthreads() would wait for the global loads in flight as well
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #define BUF_OOB 0x80000000u  // an offset no plane reaches (the launcher checks): dropped by the descriptor's range check
 // Buffer descriptor of `bytes` bytes at p.  p and bytes are workgroup-uniform, but a value that went through a VALU
@@ -243,165 +225,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void *p, uint
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes),
                                              0x00020000);
-}
-#define PW_TW(F) ((130 - (F)) / 2)
-#ifndef DWP_UNROLL
-#define DWP_UNROLL 1  // the output loop of a tile rolled: 97 instead of 121 VGPRs (bior2.2), a third workgroup per CU beside a decoder
-#endif
-
-template <int F, uint32_t LOM, uint32_t HIM>
-__global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_pf(DwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr, TileBase cb,
-                                                             uint32_t *tmax) {
-    constexpr int TW = PW_TW(F), NC = 2 * TW + F - 2, NR = 2 * DW_TH + F - 2, HC = NC / 2;
-    constexpr int OH = DW_TH / 2;        // output rows per half
-    constexpr int XR = DW_TH + F - 2;    // input rows a half needs: rows half * DW_TH .. + XR - 1 of the tile
-    static_assert(NC == 128 && DW_BLOCK == 256 && DW_TH % 2 == 0, "thread = (input column, half)");
-    constexpr int RS = HC + 1, PS = DW_TH * RS + (24 - (DW_TH * RS) % 16) % 16;  // as k_dwt_level
-    constexpr int NOUT = DW_TH * TW, NU = (NOUT + DW_BLOCK - 1) / DW_BLOCK;
-    __shared__ double s_lo[2][PS];
-    __shared__ double s_hi[2][PS];
-    __shared__ int s_row[NR];       // input row (extension applied, -1: zero) of row r of the tile whose loads come next
-    __shared__ uint32_t s_next[2];
-    __shared__ uint32_t s_amax;
-    const int tid = threadIdx.x, col = tid & 127, half = tid >> 7;
-    const uint32_t nt = gx * gy * (uint32_t)a.planes;
-    const uint32_t xcd = blockIdx.x & 7u, q8 = nt >> 3, r8 = nt & 7u;
-    const uint32_t base = xcd * q8 + (xcd < r8 ? xcd : r8), cnt = q8 + (xcd < r8 ? 1u : 0u);
-    uint32_t *const myctr = ctr + 32u * xcd;
-    const uint32_t cbase = cb.v[xcd];
-    if (tid == 0) {
-        s_next[0] = atomicAdd(myctr, 1u) - cbase;
-        s_next[1] = atomicAdd(myctr, 1u) - cbase;
-        s_amax = 0;
-    }
-    __syncthreads();
-    uint32_t k = __builtin_amdgcn_readfirstlane(s_next[0]);   // tile being worked on (position in the XCD's range)
-    uint32_t kn = __builtin_amdgcn_readfirstlane(s_next[1]);  // the one after
-    __syncthreads();
-    if (k >= cnt) return;
-
-    const bool has_m = a.mults != nullptr;
-    const uint32_t in_row_bytes = (uint32_t)a.in_w * 8u;
-    double x[XR];   // this thread's part of its input column
-    double mk_next = 1.0;
-    // rows of tile T -> s_row (threads below NR; read behind the next barrier)
-    auto rows = [&](uint32_t T) {
-        const uint32_t by = (T / gx) % gy;
-        if (tid < NR) s_row[tid] = ext_index(2 * (int)(by * DW_TH) + 2 - F + tid, a.in_h, a.mode);
-    };
-    // the loads of tile T (nothing waits for them here); s_row holds T's rows
-    auto request = [&](uint32_t T) {
-        const uint32_t bx = T % gx, plane = T / (gx * gy);
-        const int gc = ext_index(2 * (int)(bx * TW) + 2 - F + col, a.in_w, a.mode);
-        const __amdgpu_buffer_rsrc_t rs = plane_rsrc(a.in + (size_t)plane * a.in_h * a.in_w, (uint32_t)a.in_h * in_row_bytes);
-        const uint32_t coff = (uint32_t)gc * 8u;
-#pragma unroll
-        for (int r = 0; r < XR; r++) {
-            const int gr = s_row[half * DW_TH + r];
-            const uint32_t off = (gc >= 0 && gr >= 0) ? (uint32_t)gr * in_row_bytes + coff : BUF_OOB;
-            x[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
-        }
-        mk_next = has_m ? a.mults[plane % (uint32_t)a.c] : 1.0;
-    };
-    auto tile = [&](uint32_t kk, uint32_t knext) {
-        const uint32_t T = base + kk;
-        const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
-        const int oh0 = (int)(by * DW_TH), ow0 = (int)(bx * TW);
-        const double mk = mk_next;
-        // ---- axis -2 (dwt_tile's sums): x -> s_lo / s_hi.  Output row o = half * OH + oo of the tile reads tile rows
-        //      2o + F-1-j, i.e. x[2 oo + F-1-j] of this half ----
-        {
-            const int par = col & 1, hc = col >> 1;
-#pragma unroll
-            for (int oo = 0; oo < OH; oo++) {
-                double sl = 0.0, shh = 0.0;
-#pragma unroll
-                for (int j = 0; j < F; j++) {
-                    if ((LOM >> j) & 1u) sl += a.lo[j] * x[2 * oo + F - 1 - j];
-                    if ((HIM >> j) & 1u) shh += a.hi[j] * x[2 * oo + F - 1 - j];
-                }
-                s_lo[par][(half * OH + oo) * RS + hc] = sl;
-                s_hi[par][(half * OH + oo) * RS + hc] = shh;
-            }
-        }
-        const uint32_t Tn = base + min(knext, cnt - 1u);  // (past the end: the last tile again, never used)
-        rows(Tn);
-        uint32_t drawn = 0;
-        if (tid == 0) drawn = atomicAdd(myctr, 1u);  // the tile after `knext`: looked at only at the end of this one
-        lds_barrier();
-        request(Tn);
-        // ---- axis -1 from LDS (dwt_tile's sums); stores through descriptors of the two output planes ----
-        const uint32_t co_row = (uint32_t)a.enc_w * 4u, ll_row = (uint32_t)a.out_w * 8u;
-        const __amdgpu_buffer_rsrc_t rco = plane_rsrc(a.coeffs + (size_t)plane * a.enc_h * a.enc_w, (uint32_t)a.enc_h * co_row);
-        const __amdgpu_buffer_rsrc_t rll =
-            plane_rsrc(a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w, a.last ? 0u : (uint32_t)a.out_h * ll_row);
-        uint32_t amax = 0;
-#pragma unroll DWP_UNROLL
-        for (int u = 0; u < NU; u++) {
-            const int p = min(tid + u * DW_BLOCK, NOUT - 1);  // (clamped: the LDS reads stay inside the tile)
-            const int o = p / TW, wcol = p - o * TW;
-            const int oh = oh0 + o, ow = ow0 + wcol;
-            const bool valid = tid + u * DW_BLOCK < NOUT && oh < a.out_h && ow < a.out_w;
-            double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
-#pragma unroll
-            for (int j = 0; j < F; j++) {
-                const double vl = s_lo[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
-                const double vh = s_hi[(F - 1 - j) & 1][o * RS + wcol + ((F - 1 - j) >> 1)];
-                if ((LOM >> j) & 1u) { aa += a.lo[j] * vl; da += a.lo[j] * vh; }
-                if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
-            }
-            const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
-            const bool mine = valid && oh < a.ov_h && ow < a.ov_w;  // (the others: k_dwt_edge, as in dwt_tile)
-            const uint32_t o_tl = valid ? (uint32_t)oh * co_row + (uint32_t)ow * 4u : BUF_OOB;
-            if (a.last) {
-                const int32_t qaa = quant(aa, mk, a.q, has_m);
-                __builtin_amdgcn_raw_buffer_store_b32(qaa, rco, o_tl, 0, 0);
-                if (mine) amax = max(amax, iabs_u(qaa));
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, aa), rll,
-                                                      valid ? (uint32_t)oh * ll_row + (uint32_t)ow * 8u : BUF_OOB, 0, 0);
-            }
-            __builtin_amdgcn_raw_buffer_store_b32(qad, rco, o_tl + (valid ? (uint32_t)a.off_w * 4u : 0u), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(qda, rco, o_tl + (valid ? (uint32_t)a.off_h * co_row : 0u), 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(qdd, rco, o_tl + (valid ? (uint32_t)a.off_h * co_row + (uint32_t)a.off_w * 4u : 0u), 0, 0);
-            if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
-        }
-        // the tile's maximum: wavefronts meet in LDS, thread 0 stores the word of the tile behind the barrier
-        if (tmax != nullptr) {
-            for (int o = 32; o > 0; o >>= 1) amax = max(amax, (uint32_t)__shfl_xor((int)amax, o));
-            if ((tid & 63) == 0 && amax) atomicMax(&s_amax, amax);
-        }
-        if (tid == 0) s_next[0] = drawn - cbase;
-        lds_barrier();
-        if (tmax != nullptr) {
-            const __amdgpu_buffer_rsrc_t rt = plane_rsrc(tmax, nt * 4u);
-            __builtin_amdgcn_raw_buffer_store_b32((int32_t)s_amax, rt, tid == 0 ? T * 4u : BUF_OOB, 0, 0);
-        }
-    };
-    rows(base + k);
-    __syncthreads();
-    request(base + k);
-    __syncthreads();  // (s_row is written again inside the first tile)
-    // the first tile stands outside the loop (see k_idwt_level_pf)
-    tile(k, kn);
-    k = kn;
-    kn = __builtin_amdgcn_readfirstlane(s_next[0]);
-    if (tid == 0) s_amax = 0;  // (the next atomicMax on it comes behind the next tile's first barrier)
-    while (k < cnt) {
-        tile(k, kn);
-        k = kn;
-        kn = __builtin_amdgcn_readfirstlane(s_next[0]);
-        if (tid == 0) s_amax = 0;
-    }
-}
-
-// per-tile maxima of k_dwt_level_pf -> per-image maxima.  grid: (images), block 256; tpi = tiles per image
-__global__ __launch_bounds__(256) void k_tmax_fold(const uint32_t *tmax, uint32_t tpi, uint32_t *maxabs) {
-    uint32_t m = 0;
-    const uint32_t *t = tmax + (size_t)blockIdx.x * tpi;
-    for (uint32_t i = threadIdx.x; i < tpi; i += 256) m = max(m, t[i]);
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(&maxabs[blockIdx.x], m);
 }
 
 // ---- the bottom / right overhang of a float64 level, in PyWavelets' summation order -----------------------------
@@ -1258,7 +1081,7 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
         // for the next tile's samples at the top of the loop becomes a wait for these stores as well.
         const uint32_t row_bytes = (uint32_t)a.out_w * 8u;
         const __amdgpu_buffer_rsrc_t orsrc = plane_rsrc(a.out + (size_t)plane * a.out_h * a.out_w, (uint32_t)a.out_h * row_bytes);
-        const uint32_t voff0 = n < a.out_w ? (uint32_t)(2 * (kh0 + rbase)) * row_bytes + (uint32_t)n * 8u : 0x80000000u;
+        const uint32_t voff0 = n < a.out_w ? (uint32_t)(2 * (kh0 + rbase)) * row_bytes + (uint32_t)n * 8u : BUF_OOB;
 #else
         double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
 #endif
@@ -1455,7 +1278,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt1_color(IdwtKArgs a) {
 // ---- host launchers -----------------------------------------------------------------------------
 
 template <int F, uint32_t LOM, uint32_t HIM>
-static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st, TileCtr *tc) {
+static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     a.planes = planes;
     a.ov_h = a.out_h;
     a.ov_w = a.out_w;
@@ -1491,48 +1314,22 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st, TileCtr *tc) {
     while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
     if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
-    const uint32_t gx = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW), gy = (uint32_t)((a.out_h + DW_TH - 1) / DW_TH);
-    const uint32_t nt = gx * gy * (uint32_t)planes;
-    // a level with several tiles per workgroup slot: persistent workgroups that fetch a tile ahead (k_dwt_level_pf)
-    static const int pf = [] { const char *e = getenv("SPIHT_DWT_PF"); return e ? atoi(e) : 1; }();
-    static const uint32_t pf_min = [] { const char *e = getenv("SPIHT_DWT_PF_MIN"); return e ? (uint32_t)atol(e) : 20000u; }();
-    static const int num_cu = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        return n;
-    }();
-    const uint64_t lim = 1ull << 31;  // planes the 32-bit buffer offsets (and BUF_OOB beyond them) can address
-    if (pf && tc && nt >= pf_min && (uint64_t)a.in_h * a.in_w * 8u < lim && (uint64_t)a.enc_h * a.enc_w * 4u < lim &&
-        (uint64_t)a.out_h * a.out_w * 8u < lim && (a.maxabs == nullptr || (tc->tmax != nullptr && tc->tmax_cap >= (uint32_t)((a.out_w + PW_TW(F) - 1) / PW_TW(F)) * gy * (uint32_t)planes)) &&
-        planes % a.c == 0) {
-        const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : DWP_WG));
-        const uint32_t px = (uint32_t)((a.out_w + PW_TW(F) - 1) / PW_TW(F)), pt = px * gy * (uint32_t)planes;  // its own tile width
-        TileBase cb;
-        for (uint32_t x = 0; x < 8; x++) {
-            cb.v[x] = tc->base[x];
-            tc->base[x] += (pt >> 3) + (x < (pt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);  // tiles + 2 per workgroup
-        }
-        uint32_t *tmax = a.maxabs ? tc->tmax : nullptr;
-        hipLaunchKernelGGL((k_dwt_level_pf<F, LOM, HIM>), dim3(G), dim3(DW_BLOCK), 0, st, a, px, gy, tc->dev, cb, tmax);
-        if (tmax) hipLaunchKernelGGL(k_tmax_fold, dim3(planes / a.c), dim3(256), 0, st, tmax, (uint32_t)a.c * px * gy, a.maxabs);
-    } else {
-        hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
-    }
+    const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
     if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 // specialised for the zero-tap pattern of the known filter bank of that length, generic otherwise
 template <int F, uint32_t LOM, uint32_t HIM>
-static int launch_dwt_F(const DwtKArgs &a, int planes, hipStream_t st, TileCtr *tc) {
+static int launch_dwt_F(const DwtKArgs &a, int planes, hipStream_t st) {
     uint32_t lom = 0, him = 0;
     for (int j = 0; j < F; j++) {
         if (a.lo[j] != 0.0) lom |= 1u << j;
         if (a.hi[j] != 0.0) him |= 1u << j;
     }
-    if (lom == LOM && him == HIM) return launch_dwt_FM<F, LOM, HIM>(a, planes, st, tc);
-    return launch_dwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st, tc);
+    if (lom == LOM && him == HIM) return launch_dwt_FM<F, LOM, HIM>(a, planes, st);
+    return launch_dwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st);
 }
 template <int F, uint32_t LOM, uint32_t HIM>
 static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) {
@@ -1581,17 +1378,12 @@ static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st, TileCtr
     return launch_idwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st, tc);
 }
 
-// tiles of one float64 level (the words k_dwt_level_pf needs in TileCtr::tmax when the level reports a maximum)
-extern "C" uint32_t spiht_dwt_level_tiles(int out_h, int out_w, int planes) {
-    return (uint32_t)((out_w + PW_TW(18) - 1) / PW_TW(18)) * (uint32_t)((out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;  // narrowest tile
-}
-// tc: tile counters and per-tile scratch of the calling context (nullptr: a workgroup per tile)
-extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st, TileCtr *tc) {
+extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st) {
     switch (a->F) {
-    case 2: return launch_dwt_F<2, 0x3u, 0x3u>(*a, planes, st, tc);            // haar
-    case 6: return launch_dwt_F<6, 0x3Eu, 0x0Eu>(*a, planes, st, tc);          // bior2.2
-    case 10: return launch_dwt_F<10, 0x3FEu, 0x0FEu>(*a, planes, st, tc);      // bior4.4
-    case 18: return launch_dwt_F<18, 0x3FFFEu, 0x3FF8u>(*a, planes, st, tc);   // bior6.8
+    case 2: return launch_dwt_F<2, 0x3u, 0x3u>(*a, planes, st);            // haar
+    case 6: return launch_dwt_F<6, 0x3Eu, 0x0Eu>(*a, planes, st);          // bior2.2
+    case 10: return launch_dwt_F<10, 0x3FEu, 0x0FEu>(*a, planes, st);      // bior4.4
+    case 18: return launch_dwt_F<18, 0x3FFFEu, 0x3FF8u>(*a, planes, st);   // bior6.8
     default: return -1;
     }
 }
