@@ -180,14 +180,17 @@ class OverlappedCodec:
     bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder output are
     double-buffered.
 
-    Resident decoder workgroups (12 wavefronts, 96 VGPRs) leave an HBM-bound kernel three instead of six or seven
-    workgroups per CU: whichever transform shares the GPU with the decoder takes about twice its time.  Variants,
-    measured at 256 x 1080p, none better than the default's 20.2 ms per step:
-      pair="forward"    X(i) waits for I(i-1), so it runs beside A(i+1) and I(i-1) meets only the encoder kernel: 20.6
-      split_inverse     the coarse levels of I(i) (level .. 2) behind X(i) on the list-coding stream: 21.1 (the encoder
+    Resident decoder workgroups (96 VGPRs a wavefront) leave an HBM-bound kernel two or three instead of six or seven
+    workgroups per CU: whichever transform shares the GPU with the decoder loses.  The inverse transform therefore runs
+    as persistent workgroups that fetch a tile ahead (k_idwt_level_pf), and the list-coding contexts use the
+    8-wavefront build of the decoder (`decoder_waves=8`: a longer walk, a lighter neighbour): 17.6-18.0 ms per step at
+    256 x 1080p with 12 wavefronts 18.3-18.7.  Variants measured there, none better than the default:
+      pair="forward"    X(i) waits for I(i-1), so it runs beside A(i+1) and I(i-1) meets only the encoder kernel
+      split_inverse     the coarse levels of I(i) (level .. 2) behind X(i) on the list-coding stream (the encoder
                         kernel of the next batch then waits for room on CUs full of transform workgroups)
       l_priority        high stream priority for the list-coding contexts: no change
-      e_first           encoder kernel queued before the unscatter: 21.8
+      e_first           encoder kernel queued before the unscatter: worse
+      u_early           the unscatter right behind the inverse transform: worse
     `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
