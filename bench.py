@@ -157,7 +157,7 @@ def main():
     ap.add_argument("--split-inverse", type=int, default=0, help="experiment: coarse inverse levels on the list-coding stream")
     ap.add_argument("--l-priority", type=int, default=0, help="experiment: stream priority of the list-coding contexts")
     ap.add_argument("--e-first", type=int, default=0, help="experiment: encoder kernel queued before the unscatter")
-    ap.add_argument("--u-early", type=int, default=0, help="experiment: unscatter right behind the inverse transform")
+    ap.add_argument("--u-early", type=int, default=1, help="unscatter right behind the inverse transform (0: in front of the next encoder kernel)")
     ap.add_argument("--decoder-waves", type=int, default=8, choices=[8, 12],
                     help="wavefronts per decoder workgroup in the pipelined schedule (12: the library's default for single calls)")
     ap.add_argument("--streams", type=int, default=1,

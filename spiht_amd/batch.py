@@ -190,11 +190,15 @@ class OverlappedCodec:
                         kernel of the next batch then waits for room on CUs full of transform workgroups)
       l_priority        high stream priority for the list-coding contexts: no change
       e_first           encoder kernel queued before the unscatter: worse
-      u_early           the unscatter right behind the inverse transform: worse
+    and one that is the default since the inverse transform got faster:
+      u_early           the unscatter of a batch right behind its inverse transform, on that batch's list-coding
+                        context (it then runs beside the next forward transform, which loses 2 % to its scattered
+                        writes; queued in front of the next encoder kernel it met the coarse inverse levels, and a
+                        0.02 ms launch of those took 0.47 ms): 17.5-17.7 against 17.7-18.5 ms
     `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
-    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=False,
+    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=True,
                  decoder_waves=8):
         self.codec, self.B = codec, int(B)
         if pair not in ("forward", "inverse"):
