@@ -249,6 +249,21 @@ int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, in
 int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const double *M_f, double p_f, const double *A_i,
                          const double *M_i, double p_i);
 
+/* Progressive decoding of one stream to K bit budgets from ONE walk (the reference decodes a prefix per frame,
+ * make_gif.py:46-61: `decode(original_bytes[:byte_len], ...)`, i.e. K walks).  budgets_bits: host array,
+ * ascending (else SPIHT_ERR_ARG); out[k] = what spiht_decode_i32 returns for the first budgets_bits[k] bits of the
+ * stream (8 x a byte length for a byte prefix; a budget past the end means the whole stream) -- bit-exact, duplicated
+ * tree nodes included.  The walk records which list entry every stream position belongs to (as decode_with_metadata,
+ * src/encoder_decoder.rs:631-841), the records are sorted by node, and one thread per node replays the node's operations
+ * once, leaving its value in every budget it passes.
+ *   spiht_decode_budgets_i32      out: host int32 [K, c, h, w]; synchronous
+ *   spiht_decode_budgets_dev_i32  d_out: device int32 [K, c, h, w] (zero-filled by the call); asynchronous apart from
+ *                                 the upload of the stream (feeds spiht_dequant_idwt_batch_f64 with B = K) */
+int spiht_decode_budgets_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h, int64_t w,
+                             int64_t ll_h, int64_t ll_w, const uint64_t *budgets_bits, int64_t K, int32_t *out);
+int spiht_decode_budgets_dev_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
+                                 int64_t w, int64_t ll_h, int64_t ll_w, const uint64_t *budgets_bits, int64_t K, int32_t *d_out);
+
 /* Wavefronts per workgroup of the list decoder on this context: 12 (default; the shortest walk of one stream) or 8
  * (4 % slower alone, a lighter neighbour for HBM-bound kernels running beside it on other contexts -- what the
  * pipelined schedule uses for its list-coding contexts).  Output identical.  Other values: SPIHT_ERR_ARG.

@@ -41,7 +41,7 @@ SYMBOLS = [
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
     "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
-    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_ctx_set_decoder_waves", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
+    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_ctx_set_decoder_waves", "spiht_decode_budgets_i32", "spiht_decode_budgets_dev_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset", "spiht_dev_copy",
     "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_approx_shape",
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
@@ -89,6 +89,8 @@ def lib():
         L.spiht_color3_batch_f64.argtypes = [vp, vp, vp, i64, i64, vp, vp, C.c_double]
         L.spiht_ctx_set_color3.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_double]
         L.spiht_ctx_set_decoder_waves.argtypes = [vp, C.c_int]
+        L.spiht_decode_budgets_i32.argtypes = [vp, vp, u64, C.c_uint8, i64, i64, i64, i64, i64, vp, i64, vp]
+        L.spiht_decode_budgets_dev_i32.argtypes = [vp, vp, u64, C.c_uint8, i64, i64, i64, i64, i64, vp, i64, vp]
         L.spiht_ctx_set_timing.argtypes = [vp, i32]
         L.spiht_ctx_reset_timing.argtypes = [vp]
         L.spiht_ctx_stage_name.restype = C.c_char_p

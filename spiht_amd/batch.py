@@ -152,13 +152,40 @@ class BatchCodec:
             for d in (d_data, d_nbytes, d_maxn, d_img):
                 d.free()
 
-    def decode_prefixes(self, result, byte_lengths):
-        """Progressive decoding (the pattern of the reference's make_gif.py:46-61): decode the
-        prefixes `result.encoded_bytes[:k]` for every k in byte_lengths in ONE batch -> float64 [K,c,H',W'].
-        Any prefix of a SPIHT stream is a valid stream; every image of the batch is decoded by its own workgroup."""
-        pre = [EncodingResult(result.encoded_bytes[:int(k)], result.h, result.w, result.c, result.max_n, result.level)
-               for k in byte_lengths]
-        return self.decode(pre)
+    def decode_prefixes(self, result, byte_lengths, one_walk=True):
+        """Progressive decoding (the pattern of the reference's make_gif.py:46-61): the pictures of the
+        prefixes `result.encoded_bytes[:k]` for every k in byte_lengths -> float64 [K,c,H',W'] (in the order given).
+        one_walk (default): the stream is walked ONCE, to the longest prefix, and every tree node replays its operations
+        into the K coefficient arrays (spiht_decode_budgets_dev_i32); then one batched inverse transform.
+        one_walk=False: K streams in one batch, every prefix decoded by its own workgroup (K walks on K CUs)."""
+        lens = [int(k) for k in byte_lengths]
+        if not one_walk or not lens:
+            pre = [EncodingResult(result.encoded_bytes[:k], result.h, result.w, result.c, result.max_n, result.level) for k in lens]
+            return self.decode(pre)
+        g = self.geom
+        K = len(lens)
+        order = np.argsort(np.asarray(lens), kind="stable")
+        total = len(result.encoded_bytes)
+        bud = np.ascontiguousarray([8 * min(lens[i], total) for i in order], dtype=np.uint64)
+        data = np.frombuffer(result.encoded_bytes[:max(min(k, total) for k in lens)], dtype=np.uint8)
+        d_rec = DeviceArray(self.ctx, (K, self.c, g["enc_h"], g["enc_w"]), np.int32)
+        d_img = DeviceArray(self.ctx, (K, self.c, g["rec_h"], g["rec_w"]), np.float64)
+        try:
+            _lib.check(self.L.spiht_decode_budgets_dev_i32(
+                self.ctx.handle, C.c_void_p(data.ctypes.data if data.size else 0), data.size, int(result.max_n), self.c,
+                g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], C.c_void_p(bud.ctypes.data), K, C.c_void_p(d_rec.ptr)))
+            with self._color():
+                _lib.check(self.L.spiht_dequant_idwt_batch_f64(
+                    self.ctx.handle, C.c_void_p(d_rec.ptr), K, self.c, self.H, self.W, self.wid, self.mid, self._lv,
+                    float(self.settings.quantization_scale), self._mults_p, C.c_void_p(d_img.ptr)))
+            self.ctx.synchronize()
+            out = d_img.download()
+        finally:
+            d_rec.free()
+            d_img.free()
+        inv = np.empty(K, dtype=np.int64)
+        inv[order] = np.arange(K)
+        return out[inv]
 
 
 class OverlappedCodec:

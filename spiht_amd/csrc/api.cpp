@@ -25,6 +25,8 @@ int spiht_launch_unscatter(const DecArgs *a, hipStream_t st);
 int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes);
 int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
                           void *temp, size_t temp_bytes, hipStream_t st);
+int spiht_launch_budget_fold(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out,
+                             void *temp, size_t temp_bytes, const uint64_t *d_budgets, int K, int32_t *d_out, hipStream_t st);
 int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nbytes, hipStream_t st);
 int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
                         hipStream_t st);
@@ -807,6 +809,89 @@ extern "C" int spiht_decode_with_metadata_i32(spiht_ctx *ctx, const uint8_t *dat
         StageTimer t(ctx, ST_D2H);
         HIPCHK(hipMemcpyAsync(out, ctx->rec.p, (size_t)g.n * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(meta, ctx->meta.p, rows * 32, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return SPIHT_OK;
+}
+
+// Progressive decoding of ONE stream to K bit budgets (ascending) from one walk: out[kk] = what decode() returns for the
+// first budgets[kk] bits of the stream (a budget past the end: the whole stream).  The pattern of the reference's
+// make_gif.py:46-61 (`decode(original_bytes[:byte_len])` per frame), SURVEY.md 8 f-3: the K walks of K prefixes become
+// one walk with the trace of decode_with_metadata, and every tree node replays its own operations once
+// (metadata.hip: k_budget_fold).  d_out: device int32 [K, c, h, w], zero-filled here.  Asynchronous apart from the upload.
+extern "C" int spiht_decode_budgets_dev_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
+                                            int64_t w, int64_t ll_h, int64_t ll_w, const uint64_t *budgets_bits, int64_t K,
+                                            int32_t *d_out) {
+    if (!ctx || !d_out || (!data && nbytes) || !budgets_bits || K < 1 || K > 65535) return SPIHT_ERR_ARG;
+    for (int64_t k = 1; k < K; k++)
+        if (budgets_bits[k] < budgets_bits[k - 1]) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    if (g.n >= (1u << 28)) return SPIHT_ERR_TOO_LARGE;
+    if (n > 30) return SPIHT_ERR_MAGNITUDE;
+    if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t slot = std::max<uint64_t>(4, (nbytes + 3) & ~3ull);
+    const uint64_t rows = nbytes * 8 + 1;
+    size_t sort_bytes = 0;
+    if (spiht_meta_sort_temp_bytes(rows, &sort_bytes) != 0) return SPIHT_ERR_INTERNAL;
+    // trace scratch: ent[rows] u32 | 4 x u32[rows] sort buffers | act[rows] u8 | budgets | sort temp
+    const size_t o_ent = 0, o_k0 = align256(rows * 4), o_v0 = o_k0 + align256(rows * 4), o_k1 = o_v0 + align256(rows * 4),
+                 o_v1 = o_k1 + align256(rows * 4), o_act = o_v1 + align256(rows * 4), o_bud = o_act + align256(rows),
+                 o_tmp = o_bud + align256((size_t)K * 8), total = o_tmp + align256(sort_bytes);
+    CHK(ensure(ctx, ctx->data, slot));
+    CHK(ensure(ctx, ctx->nbytes, 8));
+    CHK(ensure(ctx, ctx->maxn, 4));
+    CHK(ensure(ctx, ctx->rec, (size_t)g.n * 4));
+    CHK(ensure(ctx, ctx->trace, total));
+    char *tb = (char *)ctx->trace.p;
+    CHK(clear_err(ctx));
+    {
+        StageTimer t(ctx, ST_H2D);
+        HIPCHK(hipMemsetAsync(ctx->data.p, 0, slot, ctx->stream));
+        if (nbytes) HIPCHK(hipMemcpyAsync(ctx->data.p, data, nbytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->nbytes.p, &nbytes, 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->maxn.p, &n, 1, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemcpyAsync(tb + o_bud, budgets_bits, (size_t)K * 8, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(tb + o_act, TR_NONE, rows, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // stack temporaries / the caller's arrays
+    }
+    HIPCHK(hipMemsetAsync(d_out, 0, (size_t)K * g.n * 4, ctx->stream));
+    CHK(decode_device(ctx, g, (const uint8_t *)ctx->data.p, slot, (const uint64_t *)ctx->nbytes.p,
+                      (const uint8_t *)ctx->maxn.p, 1, (int32_t *)ctx->rec.p, (uint32_t *)(tb + o_ent),
+                      (uint8_t *)(tb + o_act), rows));
+    MetaArgs ma;
+    memset(&ma, 0, sizeof(ma));
+    ma.g = g;
+    ma.rows = rows;
+    ma.tr_ent = (const uint32_t *)(tb + o_ent);
+    ma.tr_act = (const uint8_t *)(tb + o_act);
+    ma.data = (const uint8_t *)ctx->data.p;
+    ma.skey = (const uint32_t *)(tb + o_k1);
+    ma.spos = (const uint32_t *)(tb + o_v1);
+    LAUNCHCHK(spiht_launch_budget_fold(&ma, (uint32_t *)(tb + o_k0), (uint32_t *)(tb + o_v0), (uint32_t *)(tb + o_k1),
+                                       (uint32_t *)(tb + o_v1), tb + o_tmp, sort_bytes, (const uint64_t *)(tb + o_bud), (int)K,
+                                       d_out, ctx->stream));
+    return SPIHT_OK;
+}
+
+// ... with the K arrays brought to the host (int32 [K, c, h, w]); synchronous.
+extern "C" int spiht_decode_budgets_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
+                                        int64_t w, int64_t ll_h, int64_t ll_w, const uint64_t *budgets_bits, int64_t K,
+                                        int32_t *out) {
+    if (!ctx || !out || K < 1) return SPIHT_ERR_ARG;
+    Geom g;
+    CHK(make_geom(c, h, w, ll_h, ll_w, &g));
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)K * g.n * 4;
+    CHK(ensure(ctx, ctx->hrec, bytes));
+    CHK(spiht_decode_budgets_dev_i32(ctx, data, nbytes, n, c, h, w, ll_h, ll_w, budgets_bits, K, (int32_t *)ctx->hrec.p));
+    CHK(read_err(ctx));
+    {
+        StageTimer t(ctx, ST_D2H);
+        HIPCHK(hipMemcpyAsync(out, ctx->hrec.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return SPIHT_OK;

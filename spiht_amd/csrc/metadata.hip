@@ -105,6 +105,39 @@ __global__ __launch_bounds__(256) void k_meta_fold(MetaArgs a) {
     }
 }
 
+// Progressive decoding to K bit budgets from ONE walk of the stream (the pattern of the reference's make_gif.py:46-61:
+// decode(bytes[:k]) for many k).  The decoder's state after b bits is the state after the operations
+// of stream positions < b, and the sorted trace has every node's operations in stream order: one thread per node replays
+// them once and leaves the node's value in out[kk] whenever it passes budgets[kk] (ascending).  out: [K][g.n], zeroed
+// by the caller (a node without operations stays 0).
+__global__ __launch_bounds__(256) void k_budget_fold(MetaArgs a, const uint64_t *__restrict__ budgets, int K, int32_t *__restrict__ out) {
+    const uint64_t nbits = a.rows - 1;
+    const size_t n_cells = a.g.n;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < a.rows; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = a.skey[s];
+        if (key == META_KEY_NONE) continue;
+        if (s > 0 && a.skey[s - 1] == key) continue;  // not the first record of its node
+        int32_t x = 0;
+        int kk = 0;
+        for (uint64_t r = s; r < a.rows && a.skey[r] == key; r++) {
+            const uint64_t q = a.spos[r];
+            for (; kk < K && budgets[kk] <= q; kk++)  // budgets that end in front of this operation
+                if (x) out[(size_t)kk * n_cells + key] = x;
+            if (q >= nbits) continue;  // the waiting operation never got its bit
+            const uint32_t ac = a.tr_act[q], act = ac & 7u, n = ac >> 3;
+            const uint32_t bit = (a.data[q >> 3] >> (q & 7)) & 1u;
+            if (act == 1u || act == 4u) {
+                const int32_t base = n == 0 ? 1 : (int32_t)((1u << (n - 1)) + (1u << n));
+                x = bit ? base : -base;
+            } else if (act == 6u) {
+                x = meta_set_bit(x, n, bit);
+            }
+        }
+        for (; kk < K; kk++)
+            if (x) out[(size_t)kk * n_cells + key] = x;
+    }
+}
+
 extern "C" int spiht_meta_sort_temp_bytes(uint64_t rows, size_t *bytes) {
     size_t sz = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, sz, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
@@ -123,5 +156,18 @@ extern "C" int spiht_launch_metadata(const MetaArgs *a, uint32_t *keys_in, uint3
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)rows, 0u, 29u, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(k_meta_fold, dim3(grid), dim3(256), 0, st, *a);
+    return (int)hipGetLastError();
+}
+
+// the trace sorted by (node, position) as above, then k_budget_fold.  a->skey / a->spos must point to keys_out / vals_out
+extern "C" int spiht_launch_budget_fold(const MetaArgs *a, uint32_t *keys_in, uint32_t *vals_in, uint32_t *keys_out,
+                                        uint32_t *vals_out, void *temp, size_t temp_bytes, const uint64_t *d_budgets, int K,
+                                        int32_t *d_out, hipStream_t st) {
+    const uint64_t rows = a->rows;
+    const int grid = (int)std::min<uint64_t>((rows + 255) / 256, 1u << 16);
+    hipLaunchKernelGGL(k_meta_keys, dim3(grid), dim3(256), 0, st, a->tr_ent, a->tr_act, rows, keys_in, vals_in);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)rows, 0u, 29u, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_budget_fold, dim3(grid), dim3(256), 0, st, *a, d_budgets, K, d_out);
     return (int)hipGetLastError();
 }

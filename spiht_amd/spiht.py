@@ -102,6 +102,32 @@ def decode(data_u8, n, c, h, w, ll_h, ll_w):
     return out
 
 
+def decode_budgets(data_u8, n, c, h, w, ll_h, ll_w, bit_budgets):
+    """Progressive decoding from ONE walk of the stream: int32 (K, c, h, w) with
+    out[k] == decode(<the first bit_budgets[k] bits of data>, n, c, h, w, ll_h, ll_w)  (8 * L for the byte prefix
+    data[:L]; a budget past the end decodes the whole stream).  bit_budgets must be ascending.  New in this library --
+    the reference decodes one prefix per call (make_gif.py:46-61), i.e. K walks for K frames."""
+    buf = _as_u8_vec(data_u8)
+    n = _as_usize(n, "n")
+    if n > 255:
+        raise OverflowError("out of range integral type conversion attempted")
+    c, h, w = _as_usize(c, "c"), _as_usize(h, "h"), _as_usize(w, "w")
+    ll_h, ll_w = _as_usize(ll_h, "ll_h"), _as_usize(ll_w, "ll_w")
+    bud = np.ascontiguousarray([_as_usize(b, "bit_budgets") for b in bit_budgets], dtype=np.uint64)
+    if bud.size == 0:
+        return np.zeros((0, c, h, w), dtype=np.int32)
+    if ll_h <= 1 or ll_w <= 1:
+        raise PanicException("assertion failed: ll_h > 1")
+    if c == 0 or h == 0 or w == 0:
+        return np.zeros((bud.size, c, h, w), dtype=np.int32)
+    ctx = _lib.default_context()
+    out = np.empty((bud.size, c, h, w), dtype=np.int32)
+    _lib.check(_lib.lib().spiht_decode_budgets_i32(
+        ctx.handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w, ll_h, ll_w,
+        C.c_void_p(bud.ctypes.data), bud.size, C.c_void_p(out.ctypes.data)))
+    return out
+
+
 def _as_pairs(v, name, count):
     # PyO3 `Vec<(usize, usize)>`
     if isinstance(v, str):

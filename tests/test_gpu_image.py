@@ -331,13 +331,20 @@ def test_progressive_prefixes_in_one_batch(oracle):
     codec = BatchCodec(c, H, W, s, None, None)
     res = codec.encode(img[None])[0]
     ks = [0, 1, 50, 400, 3000, len(res.encoded_bytes) // 2, len(res.encoded_bytes)]
-    ims = codec.decode_prefixes(res, ks)
-    errs = []
-    for k, im in zip(ks, ims):
+    for one_walk in (True, False):  # one walk of the stream with per-node replay / K prefixes as K streams of a batch
+        ims = codec.decode_prefixes(res, ks, one_walk=one_walk)
+        errs = []
+        for k, im in zip(ks, ims):
+            one = spiht_amd.decode_image(spiht_amd.EncodingResult(res.encoded_bytes[:k], H, W, c, res.max_n, None), s)
+            assert np.array_equal(im[:, :H, :W], one), (one_walk, k)
+            errs.append(float(np.abs(one - img).mean()))
+        assert errs[-1] < errs[3] < errs[0] and errs[-1] < 0.01
+    # order of the lengths is the caller's; lengths past the end mean the whole stream
+    ks2 = [3000, 7, len(res.encoded_bytes) + 100, 400]
+    ims2 = codec.decode_prefixes(res, ks2)
+    for k, im in zip(ks2, ims2):
         one = spiht_amd.decode_image(spiht_amd.EncodingResult(res.encoded_bytes[:k], H, W, c, res.max_n, None), s)
-        assert np.array_equal(im[:, :H, :W], one)
-        errs.append(float(np.abs(one - img).mean()))
-    assert errs[-1] < errs[3] < errs[0] and errs[-1] < 0.01
+        assert np.array_equal(im[:, :H, :W], one), k
 
 
 def test_random_images_settings_and_budgets(oracle):

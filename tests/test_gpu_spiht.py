@@ -175,6 +175,37 @@ def test_decoder_with_eight_wavefronts(oracle):
         ctx.set_decoder_waves(12)
 
 
+def test_decode_budgets_one_walk(oracle):
+    """spiht_decode_budgets_i32: K bit budgets of one stream from one walk equal K separate decodes of the bit prefixes
+    (oracle: orc_decode_bits on bits[:b]) -- encoder streams and arbitrary bytes, trees with duplicated nodes included,
+    budgets at byte boundaries, inside a token (between a significance bit and its sign bit) and past the end."""
+    import spiht_amd
+    from spiht_amd.spiht import decode_budgets
+    rng = np.random.default_rng(31)
+    for (c, h, w, lh, lw) in [(1, 16, 16, 2, 2), (3, 13, 17, 3, 5), (2, 26, 38, 13, 19), (3, 96, 136, 6, 9), (3, 293, 501, 13, 19)]:
+        x = synth_coeffs(3, c, h, w, lh, lw)
+        d, n = oracle.encode(x, lh, lw, min(60000, 8 * c * h * w))
+        streams = [(d, n), (rng.integers(0, 256, 700, dtype=np.uint8).tobytes(), 6)]
+        for (data, nn) in streams:
+            bits = oracle.bytes_to_bits(data)
+            nb = len(bits)
+            bud = sorted(set([0, 1, 2, 3, 5, 8, 9, 17, 64, nb // 3, nb // 2, nb // 2 + 1, nb - 1, nb, nb + 40]
+                             + [int(v) for v in rng.integers(0, nb + 1, 12)]))
+            got = decode_budgets(data, nn, c, h, w, lh, lw, bud)
+            assert got.shape == (len(bud), c, h, w) and got.dtype == np.int32
+            for k, b in enumerate(bud):
+                ref = oracle.decode_bits(bits[:b], nn, c, h, w, lh, lw)
+                if not np.array_equal(got[k], ref):
+                    bad = np.argwhere(got[k] != ref)
+                    raise AssertionError("budget %d of %d bits, geometry %s: %d cells differ, first %s: got %d want %d"
+                                         % (b, nb, (c, h, w, lh, lw), len(bad), bad[0], got[k][tuple(bad[0])], ref[tuple(bad[0])]))
+            # the last budget is the plain decode
+            assert np.array_equal(got[-1], spiht_amd.decode(data, nn, c, h, w, lh, lw))
+    with pytest.raises(ValueError):
+        decode_budgets(d, n, c, h, w, lh, lw, [100, 50])  # not ascending
+    assert decode_budgets(d, n, c, h, w, lh, lw, []).shape == (0, c, h, w)
+
+
 def test_decode_bit_flipped_stream_odd_ll(oracle):
     """A damaged encoder stream on the geometry class of BASELINE config 2 (ll 13x19, both odd): after the first flipped
     bit the decoder walks a different path than the encoder did and the duplicated cells' list entries diverge."""
