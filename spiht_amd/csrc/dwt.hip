@@ -1362,7 +1362,12 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
         }
         if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
         else hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
-        return (int)hipGetLastError();
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess && ctr) {  // the launch did not happen: counters and book-keeping start over together
+            (void)hipMemsetAsync(tc->dev, 0, 8 * 32 * sizeof(uint32_t), st);
+            for (uint32_t x = 0; x < 8; x++) tc->base[x] = 0;
+        }
+        return (int)e;
     }
     hipLaunchKernelGGL((k_idwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     return (int)hipGetLastError();
