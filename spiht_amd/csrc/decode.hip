@@ -475,21 +475,24 @@ __device__ __forceinline__ void resolve_dups(const Geom &g, int32_t *out, const 
         const uint32_t idx = lsp_idx[t] & IDXM;
         if (!dup_cell(g, idx)) continue;
         const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
-        if (t1 != t) atomicMax(&mailA[t1], t + 1u);
+        if (t1 != t && t1 < lsp_len) atomicMax(&mailA[t1], t + 1u);  // (t1 >= lsp_len: the caller's array was not zero --
+                                                                      //  its output is wrong then, but nothing may fault)
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 2: a third entry (corner cells)
         const uint32_t idx = lsp_idx[t] & IDXM;
         if (!dup_cell(g, idx)) continue;
         const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
-        if (t1 != t && ld_l2(&mailA[t1]) != t + 1u) atomicMax(&mailB[t1], t + 1u);
+        if (t1 != t && t1 < lsp_len && ld_l2(&mailA[t1]) != t + 1u) atomicMax(&mailB[t1], t + 1u);
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 3: the owner replays
         const uint32_t idx = lsp_idx[t] & IDXM;
         if (!dup_cell(g, idx)) continue;
         if (ld_l2(&cells[idx]) - 1u != t) continue;
-        const uint32_t m2 = ld_l2(&mailA[t]), m3 = ld_l2(&mailB[t]);
+        uint32_t m2 = ld_l2(&mailA[t]), m3 = ld_l2(&mailB[t]);
+        if (m2 > lsp_len) m2 = 0;  // (as above: only a dirty array can leave such a word)
+        if (m3 > lsp_len) m3 = 0;
         uint32_t ts[3] = {0, 0, 0};
         int32_t vs[3] = {0, 0, 0};
         int cnt = 0;
