@@ -272,5 +272,7 @@ def default_context(device=None):
         c = _ctxs.get(device)
         if c is None or c.handle is None:
             c = Context(device)
+            if os.environ.get("SPIHT_DECODER_WAVES"):  # test runs of the whole suite on the 8-wavefront decoder
+                c.set_decoder_waves(int(os.environ["SPIHT_DECODER_WAVES"]))
             _ctxs[device] = c
         return c
