@@ -30,21 +30,34 @@ d_rec = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
 codec.encode_device(d_img.ptr, B, d_out.ptr, d_nbits.ptr, d_maxn.ptr)
 codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
 vp = C.c_void_p
-HOG = len(sys.argv) > 2 and sys.argv[2] == "hog"  # run the decoder while a second stream saturates HBM with forward DWTs
+# run the decoder while a second stream saturates HBM: "hog" with forward transforms, "hogi" with inverse transforms
+HOG = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] in ("hog", "hogi") else ""
 if HOG:
     ctx2 = _lib.Context(0)
     d_coef = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
+    d_pix = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
     wid, mid = L.spiht_wavelet_id(b"bior2.2"), L.spiht_mode_id(b"reflect")
+    ctx2.memset(d_coef.ptr, 0, d_coef.nbytes)
+    ctx2.synchronize()
+ctx.set_timing(True)
 for it in range(2):
+    if it == 1:
+        ctx.reset_timing()
     if HOG and it == 1:
         for _ in range(4):
-            _lib.check(L.spiht_dwt_quant_batch_f64(ctx2.handle, vp(d_img.ptr), B, C_IMG, H, W, wid, mid, LEVEL, 50.0, None,
-                                                   vp(d_coef.ptr)))
+            if HOG == "hog":
+                _lib.check(L.spiht_dwt_quant_batch_f64(ctx2.handle, vp(d_img.ptr), B, C_IMG, H, W, wid, mid, LEVEL, 50.0, None,
+                                                       vp(d_coef.ptr)))
+            else:
+                _lib.check(L.spiht_dequant_idwt_batch_f64(ctx2.handle, vp(d_coef.ptr), B, C_IMG, H, W, wid, mid, LEVEL, 50.0, None,
+                                                          vp(d_pix.ptr)))
     _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B,
                                         C_IMG, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], vp(d_rec.ptr)))
 ctx.synchronize()
 if HOG:
     ctx2.synchronize()
+ctx.set_timing(False)
+print("decoder kernel (HIP events): %.2f ms for %d images" % (ctx.timing()["decode_lists"][0], B))
 words = (C.c_uint32 * 64)()
 L.spiht_debug_words.argtypes = [vp, vp]
 _lib.check(L.spiht_debug_words(ctx.handle, words))
