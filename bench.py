@@ -130,8 +130,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
     ap.add_argument("--distinct", type=int, default=0,
                     help="distinct synthetic images per GPU, cycled through the batch (0 = default: every image of the batch "
