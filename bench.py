@@ -116,9 +116,10 @@ def spawn_ranks(n):
     port = s.getsockname()[1]
     s.close()
     procs = []
+    token = "%d.%d" % (os.getpid(), time.time_ns())  # tells this job's ranks from another job's on nearby ports (dist.py)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), SPIHT_JOB_TOKEN=token)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0

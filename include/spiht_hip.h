@@ -264,6 +264,14 @@ int spiht_decode_budgets_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbyte
 int spiht_decode_budgets_dev_i32(spiht_ctx *ctx, const uint8_t *data, uint64_t nbytes, uint8_t n, int64_t c, int64_t h,
                                  int64_t w, int64_t ll_h, int64_t ll_w, const uint64_t *budgets_bits, int64_t K, int32_t *d_out);
 
+/* The context's (recursive) mutex held across a SEQUENCE of calls by one thread: spiht_ctx_set_color3 is state of the
+ * context, so set / image calls / clear must not interleave with another thread's calls on the same context (those
+ * would be coded in the wrong colour model, silently).  spiht_amd.color_models.fused brackets its block with these.
+ * Unlock from the thread that locked.  (The reference's colour step is a pure function of the pixel array,
+ * spiht_wrapper.py:158-160 -- there is no shared state to protect there.) */
+int spiht_ctx_lock(spiht_ctx *ctx);
+int spiht_ctx_unlock(spiht_ctx *ctx);
+
 /* Wavefronts per workgroup of the list decoder on this context: 12 (default; the shortest walk of one stream) or 8
  * (4 % slower alone, a lighter neighbour for HBM-bound kernels running beside it on other contexts -- what the
  * pipelined schedule uses for its list-coding contexts).  Output identical.  Other values: SPIHT_ERR_ARG.
@@ -313,6 +321,9 @@ int spiht_comm_info(spiht_comm *comm, int *world, int *rank, int *rccl_version);
 int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *comm, const uint8_t *d_slots, const uint64_t *d_nbits,
                          const uint8_t *d_max_n, int64_t B, uint64_t slot_stride, uint8_t *d_all_slots,
                          uint64_t *d_all_nbits, uint8_t *d_all_max_n);
+/* The RCCL shared library this process uses: the soname that was loaded, or every candidate tried with the loader's
+ * reason when none could be ("" before the first spiht_comm_* call).  For the job's log line. */
+const char *spiht_rccl_library(void);
 /* Host-side job control over the same communicator (both block): every rank has arrived and its context's queue is
  * empty; *value becomes the maximum over ranks. */
 int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *comm);

@@ -1,30 +1,30 @@
 /*
  * oracle/color_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
  *
- * CPU twin of the GPU's colour model change (spiht_amd/csrc/dwt.hip: color3_px / k_color3; reference call sites
- * spiht/spiht_wrapper.py:158-160, :278-279 -> spiht/color_models.py:6-13 -> colour-science 0.4.4, which is absent here:
- * COLOUR PARITY IS UNPINNED).  It includes the very header the kernels include (csrc/spow.h, spow_tables.h) and
- * performs the same float64 operations in the same order (this file is built with -ffp-contract=off, fused
- * multiply-adds are explicit), so the device result can be checked bit for bit, and the power function's accuracy
- * can be measured on the CPU.
+ * The colour model change of the reference's wrapper (spiht/spiht_wrapper.py:158-160, :278-279 ->
+ * spiht/color_models.py:6-13 -> colour-science 0.4.4 `colour.convert`, which is absent here: COLOUR PARITY IS UNPINNED
+ * beyond the published known answer of the XYZ -> IPT half, tests/test_oracle.py) restated on the CPU with the C
+ * library's pow(): per pixel w = M * spow(A * u, p), spow(x, p) = sign(x) |x|^p (colour-science's `spow`), numpy's
+ * dot order.  Independent of the product: nothing of spiht_amd/ is included -- the GPU kernels use their own power
+ * function (csrc/spow.h) and are held to this one within a stated number of units in the last place.
  */
 #include <math.h>
 #include <stdint.h>
 
-#define SPOW_TABLE_QUAL static const
-#include "../spiht_amd/csrc/spow_tables.h"
-#include "../spiht_amd/csrc/spow.h"
+static double spow_libm(double x, double p) {
+    if (x == 0.0) return 0.0;
+    const double m = pow(fabs(x), p);
+    return x < 0.0 ? -m : m;
+}
 
-double orc_spow(double x, double p) { return spow_signed(x, p, SPOW_INV, SPOW_LOG2C, SPOW_EXP2); }
-
-/* in / out: [3][npix] planes; A, M: row-major 3x3; w = M * spow(A * u, p) per pixel, numpy's dot order */
+/* in / out: [3][npix] planes; A, M: row-major 3x3 */
 void orc_color3(const double *in, double *out, int64_t npix, const double *A, const double *M, double p) {
     for (int64_t t = 0; t < npix; t++) {
         const double u0 = in[t], u1 = in[npix + t], u2 = in[2 * npix + t];
         double v[3];
         for (int r = 0; r < 3; r++) {
             const double x = (u0 * A[3 * r] + u1 * A[3 * r + 1]) + u2 * A[3 * r + 2];
-            v[r] = orc_spow(x, p);
+            v[r] = spow_libm(x, p);
         }
         out[t] = (v[0] * M[0] + v[1] * M[1]) + v[2] * M[2];
         out[npix + t] = (v[0] * M[3] + v[1] * M[4]) + v[2] * M[5];

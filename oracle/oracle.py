@@ -25,8 +25,7 @@ MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4}
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c", "color_oracle.c",
-                                             "../spiht_amd/csrc/spow.h", "../spiht_amd/csrc/spow_tables.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c", "color_oracle.c")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO
@@ -205,16 +204,9 @@ def set_codes(x, ll_h, ll_w):
     return d, l, has.astype(bool)
 
 
-def spow(x, p):
-    """the colour kernels' signed power sign(x)|x|^p (csrc/spow.h), on the CPU"""
-    L = lib()
-    L.orc_spow.argtypes = [C.c_double, C.c_double]
-    L.orc_spow.restype = C.c_double
-    return L.orc_spow(float(x), float(p))
-
-
 def color3(img, A, M, p):
-    """CPU twin of the GPU's colour model change (k_color3): img float64 [3,...] -> same shape"""
+    """the colour model change w = M * spow(A * u, p) per pixel with the C library's pow() (color_oracle.c: independent of
+    the product's power function): img float64 [3,...] -> same shape"""
     img = np.ascontiguousarray(img, dtype=np.float64)
     out = np.empty_like(img)
     A, M = np.ascontiguousarray(A, np.float64), np.ascontiguousarray(M, np.float64)

@@ -47,7 +47,7 @@ SYMBOLS = [
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
-    "spiht_comm_barrier", "spiht_comm_allreduce_max_f64",
+    "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
 ]
 
 
@@ -138,6 +138,10 @@ def lib():
         L.spiht_gather_streams.argtypes = [vp, vp, vp, vp, vp, i64, u64, vp, vp, vp]
         L.spiht_comm_barrier.argtypes = [vp, vp]
         L.spiht_comm_allreduce_max_f64.argtypes = [vp, vp, C.POINTER(C.c_double)]
+        L.spiht_rccl_library.restype = C.c_char_p
+        L.spiht_rccl_library.argtypes = []
+        L.spiht_ctx_lock.argtypes = [vp]
+        L.spiht_ctx_unlock.argtypes = [vp]
         _lib = L
         return _lib
 
@@ -179,6 +183,14 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def lock(self):
+        """hold the context's (recursive) mutex across several calls of this thread: other threads' calls on the context
+        wait until unlock() -- for settings that are state of the context (color_models.fused)"""
+        check(self._lib.spiht_ctx_lock(self.handle))
+
+    def unlock(self):
+        check(self._lib.spiht_ctx_unlock(self.handle))
 
     def set_decoder_waves(self, waves):
         """wavefronts per decoder workgroup on this context: 12 (default, fastest alone) or 8 (lighter beside HBM-bound

@@ -1,38 +1,89 @@
 """Colour conversion used by SpihtSettings.color_model (reference: spiht/color_models.py:6-13, which calls the
 third-party colour-science 0.4.4 `colour.convert`).
 
-PARITY UNPINNED: colour-science is absent from this image and the reference holds no test that sets
-`color_model`, so the exact graph `colour.convert(x, 'RGB', 'IPT')` walks cannot be checked (SURVEY.md 8c,
-App. F).  What is implemented is the published Ebner-Fairchild (1998) IPT transform applied to linear RGB with
-sRGB primaries / D65; it is validated for self-consistency (round trip) only.  `convert` is host-side numpy (API
-parity, checker); the codec applies the change on the GPU inside level 1 of the transforms (`fused`).
+PARITY UNPINNED, with one published anchor: colour-science is absent from this image and the reference holds no test
+that sets `color_model`, so the exact graph `colour.convert(x, 'RGB', 'IPT')` walks cannot be run.
+What is implemented is the published Ebner-Fairchild (1998) IPT transform applied to linear RGB with sRGB primaries / D65:
+  * XYZ -> IPT half (M1, exponent 0.43, M2 below -- the constants of colour-science's `XYZ_to_IPT`): pinned by the known
+    answer of that function's documentation, XYZ [0.20654008, 0.12197225, 0.05136952] -> IPT [0.38426191, 0.38487306,
+    0.18886838] (tests/test_oracle.py on the CPU, tests/test_gpu_image.py on the device kernel);
+  * RGB -> XYZ half: a choice of matrix that nothing here can check (see RGB_XYZ_MATRICES).
+`convert` is host-side numpy (API parity, checker); the codec applies the change on the GPU inside level 1 of the
+transforms (`fused`).
 """
+import os
+
 import numpy as np
 
 SUPPORTED_MODELS = {"RGB", "IPT"}
 
-# linear sRGB (D65) -> CIE XYZ
-_RGB2XYZ = np.array([[0.4124564, 0.3575761, 0.1804375],
-                     [0.2126729, 0.7151522, 0.0721750],
-                     [0.0193339, 0.1191920, 0.9503041]])
+# linear sRGB (D65) <-> CIE XYZ.  Two published forms, selectable (set_rgb_xyz / SPIHT_RGB_XYZ):
+#   "iec"        the 4-decimal matrices of IEC 61966-2-1:1999, each direction as printed in the standard (the inverse is
+#                NOT the numerical inverse of the forward matrix).  To the best of our knowledge these are the constants
+#                of colour-science's sRGB colourspace (colour/models/rgb/datasets/srgb.py: MATRIX_sRGB_TO_XYZ /
+#                MATRIX_XYZ_TO_sRGB, `use_derived` off), i.e. what `colour.convert(x, 'RGB', 'IPT')` multiplies by -- stated
+#                from memory, the package cannot be consulted here.  Default for that reason.
+#   "lindbloom"  the 7-digit matrix derived from the sRGB primaries and the D65 white (brucelindbloom.com, "RGB/XYZ
+#                Matrices"); the way back is its numerical inverse.  Rounds 1-2 of this repository used it.
+# The two differ in the 4th decimal: coded pictures differ, decoded pictures are equally good.  colour-science also
+# passes XYZ through a von Kries adaptation between two EQUAL whites (numerically the identity to ~1e-16) and applies
+# the two 3x3 matrices one after the other; here they are multiplied into one.  None of this is checkable without the
+# package, which is why the whole step stays "parity unpinned".
+RGB_XYZ_MATRICES = {
+    "iec": (np.array([[0.4124, 0.3576, 0.1805],
+                      [0.2126, 0.7152, 0.0722],
+                      [0.0193, 0.1192, 0.9505]]),
+            np.array([[3.2406, -1.5372, -0.4986],
+                      [-0.9689, 1.8758, 0.0415],
+                      [0.0557, -0.2040, 1.0570]])),
+    "lindbloom": (np.array([[0.4124564, 0.3575761, 0.1804375],
+                            [0.2126729, 0.7151522, 0.0721750],
+                            [0.0193339, 0.1191920, 0.9503041]]), None),
+}
+_rgb_xyz_name = None
+_RGB2XYZ = _XYZ2RGB = None
+
+
+def set_rgb_xyz(name):
+    """choose the linear-sRGB <-> XYZ matrices ("iec" or "lindbloom", see RGB_XYZ_MATRICES); returns the previous name"""
+    global _rgb_xyz_name, _RGB2XYZ, _XYZ2RGB
+    if name not in RGB_XYZ_MATRICES:
+        raise ValueError("unknown RGB <-> XYZ matrices %r: one of %s" % (name, sorted(RGB_XYZ_MATRICES)))
+    prev, _rgb_xyz_name = _rgb_xyz_name, name
+    fwd, inv = RGB_XYZ_MATRICES[name]
+    _RGB2XYZ, _XYZ2RGB = fwd, (np.linalg.inv(fwd) if inv is None else inv)
+    return prev
+
+
+set_rgb_xyz(os.environ.get("SPIHT_RGB_XYZ", "iec"))
+
+# XYZ (D65) -> LMS and LMS' -> IPT of the IPT colour space (Ebner & Fairchild 1998; colour-science:
+# MATRIX_IPT_XYZ_TO_LMS, MATRIX_IPT_LMS_P_TO_IPT); the ways back are their numerical inverses (as colour-science's)
 _XYZ2LMS = np.array([[0.4002, 0.7075, -0.0807],
                      [-0.2280, 1.1500, 0.0612],
                      [0.0, 0.0, 0.9184]])
 _LMS2IPT = np.array([[0.4000, 0.4000, 0.2000],
                      [4.4550, -4.8510, 0.3960],
                      [0.8056, 0.3572, -1.1628]])
+IPT_EXPONENT = 0.43
+
+
+def xyz_to_ipt(xyz):
+    """the XYZ -> IPT half on its own (last axis = 3): the part a published known answer pins"""
+    lms = np.asarray(xyz, dtype=np.float64) @ _XYZ2LMS.T
+    return (np.sign(lms) * np.abs(lms) ** IPT_EXPONENT) @ _LMS2IPT.T
 
 
 def _rgb_to_ipt(x):
     lms = x @ (_XYZ2LMS @ _RGB2XYZ).T
-    lmsp = np.sign(lms) * np.abs(lms) ** 0.43
+    lmsp = np.sign(lms) * np.abs(lms) ** IPT_EXPONENT
     return lmsp @ _LMS2IPT.T
 
 
 def _ipt_to_rgb(x):
     lmsp = x @ np.linalg.inv(_LMS2IPT).T
-    lms = np.sign(lmsp) * np.abs(lmsp) ** (1.0 / 0.43)
-    return lms @ np.linalg.inv(_XYZ2LMS @ _RGB2XYZ).T
+    lms = np.sign(lmsp) * np.abs(lmsp) ** (1.0 / IPT_EXPONENT)
+    return lms @ (_XYZ2RGB @ np.linalg.inv(_XYZ2LMS)).T
 
 
 def convert(im, src, dest):
@@ -55,9 +106,9 @@ def convert(im, src, dest):
 def _params(src, dest):
     """(A, M, p) of w = M * spow(A * u, p) for one direction"""
     if (src, dest) == ("RGB", "IPT"):
-        A, M, p = _XYZ2LMS @ _RGB2XYZ, _LMS2IPT, 0.43
+        A, M, p = _XYZ2LMS @ _RGB2XYZ, _LMS2IPT, IPT_EXPONENT
     else:
-        A, M, p = np.linalg.inv(_LMS2IPT), np.linalg.inv(_XYZ2LMS @ _RGB2XYZ), 1.0 / 0.43
+        A, M, p = np.linalg.inv(_LMS2IPT), _XYZ2RGB @ np.linalg.inv(_XYZ2LMS), 1.0 / IPT_EXPONENT
     return np.ascontiguousarray(A, np.float64), np.ascontiguousarray(M, np.float64), float(p)
 
 
@@ -79,14 +130,25 @@ class fused:
             Af, Mf, pf = _params("RGB", self.model)
             Ai, Mi, pi = _params(self.model, "RGB")
             vp = C.c_void_p
-            _lib.check(_lib.lib().spiht_ctx_set_color3(self.ctx.handle, vp(Af.ctypes.data), vp(Mf.ctypes.data), pf,
-                                                       vp(Ai.ctypes.data), vp(Mi.ctypes.data), pi))
+            # The setting is state of the context, and the calls of the block are separate C calls: the context's mutex is
+            # held from the set to the clear, so no other thread's call on this context can fall between them (it would
+            # be coded in this colour model -- or this block's calls in none -- without any error).
+            self.ctx.lock()
+            try:
+                _lib.check(_lib.lib().spiht_ctx_set_color3(self.ctx.handle, vp(Af.ctypes.data), vp(Mf.ctypes.data), pf,
+                                                           vp(Ai.ctypes.data), vp(Mi.ctypes.data), pi))
+            except BaseException:
+                self.ctx.unlock()
+                raise
         return self
 
     def __exit__(self, *exc):
         if self.on:
             from . import _lib
-            _lib.check(_lib.lib().spiht_ctx_set_color3(self.ctx.handle, None, None, 0.0, None, None, 0.0))
+            try:
+                _lib.check(_lib.lib().spiht_ctx_set_color3(self.ctx.handle, None, None, 0.0, None, None, 0.0))
+            finally:
+                self.ctx.unlock()
         return False
 
 

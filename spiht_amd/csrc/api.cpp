@@ -17,7 +17,9 @@
 
 extern "C" {
 int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st);
-int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
+int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, const D1Cover *cov,
+                         hipStream_t st);
+void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
 int spiht_launch_decode_w8(const DecArgs *a, hipStream_t st);  // the 8-wavefront build of decode.hip
@@ -514,8 +516,10 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
                                uint64_t *d_nbits, uint8_t *d_maxn);
 
 // Encode B device-resident coefficient arrays.  max_bits already validated; queues work on ctx->stream.
+// cov: the D codes level 1 of the forward transform has left in ctx->dmsb already (nullptr: none)
 static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int B, uint64_t max_bits_in, uint8_t *d_out,
-                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false) {
+                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false,
+                         const D1Cover *cov = nullptr) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
     const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;  // encoder_decoder.rs:196
@@ -537,7 +541,7 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
     }
     {
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, cov, ctx->stream));
     }
     return encode_lists_device(ctx, g, d_x, (const uint8_t *)ctx->dmsb.p, (const uint8_t *)ctx->lmsb.p,
                                (const uint32_t *)ctx->maxabs.p, B, max_bits, caps, nslots, lp, d_out, slot_stride, d_nbits,
@@ -950,7 +954,7 @@ extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64
     }
     {
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, (int)B, d_x, d_dmsb, d_lmsb, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, (int)B, d_x, d_dmsb, d_lmsb, nullptr, ctx->stream));
     }
     return SPIHT_OK;
 }
@@ -1010,8 +1014,13 @@ static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, 
 // pixels [planes,H,W] -> quantised packed array [planes,enc_h,enc_w]
 // f32: d_img holds float pixels and the transform runs in single precision, as PyWavelets does for float32 / float16
 // input (every level's input must then be at least as long as the filter: SPIHT_ERR_ARG otherwise)
+// d_dmsb / cov: the significance pyramid will be built over d_coeffs next (into d_dmsb [planes, enc_h, enc_w]): level 1
+// then writes the D codes it has at hand (dwt.hip: dwt_tile<.., EMIT>) and *cov says which (cov->on = 0: none)
 static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
-                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false) {
+                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false,
+                       uint8_t *d_dmsb = nullptr, D1Cover *cov = nullptr) {
+    if (cov) memset(cov, 0, sizeof(*cov));
+    static const bool emit_on = [] { const char *e = getenv("SPIHT_D1_EMIT"); return e ? atoi(e) != 0 : true; }();
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
     if (f32) {
@@ -1064,6 +1073,11 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         if (color && l == 1) { a.color = 1; a.col = ctx->col_fwd; }
         memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
         memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
+        // (two levels at least: the parents of the level-1 cells are then depth-1 nodes outside the root block)
+        if (l == 1 && ig.L >= 2 && d_dmsb && cov && emit_on && !f32 && !a.color) {
+            a.dmsb = d_dmsb;
+            spiht_dwt_d1_cover(&a, cov);
+        }
         {
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
             LAUNCHCHK(spiht_launch_dwt_level(&a, planes, ctx->stream));
@@ -1276,11 +1290,13 @@ static int encode_image_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int
             co = (int32_t *)ctx->coeffs.p;
         }
         CHK(ensure(ctx, ctx->maxabs, (size_t)nb * 4));
+        CHK(ensure(ctx, ctx->dmsb, (size_t)nb * g.n));  // (before the transform: level 1 writes D codes into it)
         HIPCHK(hipMemsetAsync(ctx->maxabs.p, 0, (size_t)nb * 4, ctx->stream));
+        D1Cover cov;
         CHK(dwt_forward(ctx, (const double *)((const char *)d_img + (size_t)b0 * c * H * W * esz), nb * (int)c, (int)c, ig, wavelet,
-                        mode, q_scale, d_mults, co, (uint32_t *)ctx->maxabs.p, f32));
+                        mode, q_scale, d_mults, co, (uint32_t *)ctx->maxabs.p, f32, (uint8_t *)ctx->dmsb.p, &cov));
         CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
-                          d_max_n + b0, true));
+                          d_max_n + b0, true, &cov));
     }
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
@@ -1503,11 +1519,12 @@ extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, 
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         int32_t *co = d_coeffs + (size_t)b0 * g.n;
+        D1Cover cov;
         CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
-                        d_maxabs + b0));
+                        d_maxabs + b0, false, d_dmsb ? d_dmsb + (size_t)b0 * g.n : nullptr, &cov));
         if (!d_dmsb) continue;  // transform + max|coefficient| only: the pyramid is queued elsewhere (spiht_pyramid_batch_i32)
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, &cov, ctx->stream));
     }
     return SPIHT_OK;
 }
@@ -1582,6 +1599,21 @@ extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, i
 // Width of the list decoder's workgroups on this context.  12 wavefronts (default) walk one stream fastest; 8 take 4 %
 // longer alone but leave the HBM-bound kernels that share the CUs with the decoder more room -- the setting of the
 // list-coding contexts of the pipelined schedule (spiht_amd/batch.py: OverlappedCodec).  Same output either way.
+// The context's mutex for a SEQUENCE of calls (it is recursive: the calls inside take it again).  What needs it: a
+// setting that is state of the context and must hold for exactly the calls of one caller -- the colour model
+// (spiht_ctx_set_color3 ... image calls ... clear): without it another thread's call on the same context could run
+// between the set and the clear and be coded in the wrong colour model.  Unlock from the thread that locked.
+extern "C" int spiht_ctx_lock(spiht_ctx *ctx) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    ctx->mu.lock();
+    return SPIHT_OK;
+}
+extern "C" int spiht_ctx_unlock(spiht_ctx *ctx) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    ctx->mu.unlock();
+    return SPIHT_OK;
+}
+
 extern "C" int spiht_ctx_set_decoder_waves(spiht_ctx *ctx, int waves) {
     if (!ctx || (waves != 8 && waves != 12)) return SPIHT_ERR_ARG;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1723,23 +1755,29 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GetVersion)(int *) = nullptr;
+    const char *(*GetLastError)(ncclComm_t) = nullptr;  // optional (newer RCCL)
 };
 static RcclApi g_rccl;
 static std::mutex g_rccl_mu;
+
+static std::string g_rccl_name;   // the soname that was loaded, or what was tried and why each failed
 
 static int rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.h) return SPIHT_OK;
     const char *names[] = {getenv("SPIHT_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void *h = nullptr;
+    std::string tried;
     for (const char *n : names) {
         if (!n || !*n) continue;
         h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (h) break;
+        if (h) { g_rccl_name = n; break; }
+        const char *e = dlerror();
+        tried += std::string(tried.empty() ? "" : "; ") + n + ": " + (e ? e : "?");
     }
     if (!h) {
-        const char *e = dlerror();
-        g_hip_err = std::string("cannot load librccl: ") + (e ? e : "?");
+        g_rccl_name = "not loaded (" + tried + ")";
+        g_hip_err = "cannot load librccl, tried " + tried;
         return SPIHT_ERR_HIP;
     }
     RcclApi a;
@@ -1759,6 +1797,7 @@ static int rccl_load() {
     RSYM(GetErrorString, "ncclGetErrorString");
     RSYM(GetVersion, "ncclGetVersion");
 #undef RSYM
+    *(void **)(&a.GetLastError) = dlsym(h, "ncclGetLastError");
     g_rccl = a;
     return SPIHT_OK;
 }
@@ -1779,6 +1818,13 @@ struct spiht_comm {
 };
 
 static_assert(SPIHT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+
+// Which RCCL library serves this process: the soname dlopen took, or -- when none could be loaded -- every candidate
+// tried with the loader's reason.  Empty before the first spiht_comm_* call.
+extern "C" const char *spiht_rccl_library(void) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    return g_rccl_name.c_str();
+}
 
 extern "C" int spiht_comm_unique_id(uint8_t *id) {
     if (!id) return SPIHT_ERR_ARG;
@@ -1802,7 +1848,13 @@ extern "C" int spiht_comm_create(spiht_ctx *ctx, const uint8_t *id, int world, i
     c->device = ctx->device;
     ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
     if (r != ncclSuccess) {
-        g_hip_err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r);
+        // the result's name and, where this RCCL has it, the text of the last error it logged (the actual reason)
+        g_hip_err = "ncclCommInitRank(world " + std::to_string(world) + ", rank " + std::to_string(rank) + ", device " +
+                    std::to_string(ctx->device) + ", " + g_rccl_name + "): " + g_rccl.GetErrorString(r);
+        if (g_rccl.GetLastError) {
+            const char *le = g_rccl.GetLastError(nullptr);
+            if (le && *le) g_hip_err += std::string(" -- ") + le;
+        }
         delete c;
         return SPIHT_ERR_HIP;
     }

@@ -1266,6 +1266,10 @@ void k_decode(DecArgs a) {
         // With an odd ll_h or ll_w some cells are owned by two or three list entries (dup_cell); those are left out here
         // and resolved below.
         const bool dups = ((g.ll_h | g.ll_w) & 1) != 0;
+        // On the capacity-error path (sh.bad: reported below, the output is void) the length kept counting past the
+        // list's end: what follows must stay inside this slot's LSP -- and inside its LIP buffers, which resolve_dups
+        // uses as mail words indexed by LSP position (caps.lsp <= caps.lip whenever no error is pending).
+        lsp_len = min(lsp_len, min(a.caps.lsp, a.caps.lip));
         // Four entries per thread per batch, and the loads of the next batch are issued BEFORE the stores of this one:
         // loads and stores retire through one in-order counter (vmcnt), so a load issued after a scattered store
         // cannot be waited for without waiting for that store to be acknowledged (a plain loop pays load latency +

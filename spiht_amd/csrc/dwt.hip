@@ -57,6 +57,12 @@ __device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, 
 // atomic-bound as HBM-bound).  So: one atomic per workgroup (the wavefronts meet in an LDS word first), and none when
 // the word already holds as much (MAXLOOK: 0 no look, 1 a cached load, 2 a load the atomics' coherence point answers;
 // a stale answer only costs a spare atomic).  `s_m` must have been zeroed before an earlier barrier.
+// MAXLOOK 1 relies on this: the word is only ever RAISED between two zero-fills (hipMemsetAsync in front of every
+// transform, api.cpp), and a zero-fill is a kernel / copy of its own on the same stream -- the caches that could hold the
+// word (the CU's vector L1, and the per-XCD L2 for lines another XCD wrote) are invalidated at the kernel boundary in
+// front of this launch, so a look can return an OLD value of this launch's epoch (lower: a spare atomic) but never one
+// from before the zero-fill (higher: a lost maximum).  tests/test_gpu_dwt.py::test_maxabs_small_batch_after_large_batch
+// runs exactly the case that would show it: large magnitudes, then small ones, same context and buffer.
 #ifndef MAXLOOK
 #define MAXLOOK 1
 #endif
@@ -110,7 +116,17 @@ __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 
 // a zero tap contributes exactly nothing (0*x added to the running sum), so skipping it changes no bit and
 // removes a third (bior2.2) to a fifth of the float64 arithmetic.
 // One tile of k_dwt_level.
-template <int F, uint32_t LOM, uint32_t HIM, int PS, int NR>
+// EMIT: the tile also writes the significance-pyramid code D(p) = 1 + msb of max|x| over the 2x2 block of cells
+// (2i..2i+1, 2j..2j+1) of the packed array (encoder_decoder.rs:66-74, :78-99: the offspring of p = (i, j)) for every such
+// block a wavefront holds whole -- the quantised values are at hand here, the pyramid pass (pyramid.hip: k_pyr_12<true>)
+// would otherwise read them back from memory.  No barrier, no LDS: a wavefront computes D1_ROWS = 3 consecutive output rows
+// (one per trip of the position loop) at 64 columns, so a thread holds both rows of one block row per band in
+// registers; the position of the top bit of a maximum is that of the OR, so the four magnitudes are ORed -- two in
+// the thread, the neighbour column's by one cross-lane read -- and the lane of the block's first column stores the
+// byte.  Blocks whose rows lie in two wavefronts' groups or whose columns in two tiles are left to the pyramid pass,
+// which evaluates the same rule (common.h: d1_rows_covered / d1_cols_covered).  (A form that folded EVERY block of the
+// tile through LDS behind the barrier of the max|coefficient| reduction cost the kernel 9 %: 4.34 instead of 3.99 ms.)
+template <int F, uint32_t LOM, uint32_t HIM, int PS, int NR, bool EMIT>
 __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS], double (&s_hi)[2][PS], int (&s_row)[NR],
                                          uint32_t tbx, uint32_t tby, uint32_t tbz) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
@@ -162,11 +178,17 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
     double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
     uint32_t amax = 0;
+    constexpr int NU = (DW_TH * DW_TW + DW_BLOCK - 1) / DW_BLOCK;  // output positions per thread
+    static_assert(!EMIT || (DW_TW == D1_COLS && DW_TW == 64 && NU == D1_ROWS && D1_ROWS == 3 && DW_TH == D1_ROWS * (DW_BLOCK / 64)),
+                  "a wavefront = D1_ROWS rows of D1_COLS output positions");
+    uint32_t mag[NU][3];  // EMIT: |quantised 'ad', 'da', 'dd'| of this thread's positions (0 outside the bands)
 #pragma unroll
-    for (int u = 0; u < (DW_TH * DW_TW + DW_BLOCK - 1) / DW_BLOCK; u++) {
+    for (int u = 0; u < NU; u++) {
         const int p = tid + u * DW_BLOCK;
-        const int o = p / DW_TW, wcol = p % DW_TW;
+        // EMIT: wavefront w takes rows 3w .. 3w+2 instead of w, w+4, w+8 (same access pattern: a wavefront = one row)
+        const int o = EMIT ? (tid >> 6) * NU + u : p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
+        if (EMIT) { mag[u][0] = 0; mag[u][1] = 0; mag[u][2] = 0; }
         if (o >= DW_TH || oh >= a.out_h || ow >= a.out_w) continue;
         // x~ index 2*ow+1-j  ->  tile column 2*wcol + F-1-j  ->  parity (F-1-j)&1, half-column wcol + (F-1-j)/2
         double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
@@ -178,6 +200,7 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }
         const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
+        if (EMIT) { mag[u][0] = iabs_u(qad); mag[u][1] = iabs_u(qda); mag[u][2] = iabs_u(qdd); }
         // the few outputs of the bottom / right overhang whose sum depends on PyWavelets' tap order are computed again
         // by k_dwt_edge, which overwrites them and accounts for their magnitude
         const bool mine = oh < a.ov_h && ow < a.ov_w;
@@ -193,12 +216,30 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
         if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
+    if (EMIT) {
+        // A band's cells sit at array rows R_b + oh, columns C_b + ow, and the block of a node starts at even array
+        // coordinates (the tile origin is even): of this wavefront's rows 3w, 3w+1, 3w+2 the block row starts at the one
+        // with the parity of R_b, of the columns at those with the parity of C_b.  It must end inside what this kernel
+        // wrote of the band (lim: not the rows / columns k_dwt_edge computes again).
+        const int wv = tid >> 6, wcol = tid & 63;
+        const int lim_h = min(a.out_h, a.ov_h), lim_w = min(a.out_w, a.ov_w);
+        uint8_t *__restrict__ dm = a.dmsb + (size_t)plane * a.enc_h * a.enc_w;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int Rb = b == 0 ? 0 : a.off_h, Cb = b == 1 ? 0 : a.off_w;  // 0: 'ad', 1: 'da', 2: 'dd'
+            const int u0 = (wv * NU + Rb) & 1, o0 = wv * NU + u0;
+            uint32_t v = u0 ? (mag[1][b] | mag[2][b]) : (mag[0][b] | mag[1][b]);
+            v |= (uint32_t)__shfl_down((int)v, 1);  // the column to the right (all lanes take part)
+            if ((wcol & 1) == (Cb & 1) && wcol + 1 < DW_TW && oh0 + o0 + 1 < lim_h && ow0 + wcol + 1 < lim_w)
+                dm[(size_t)((Rb + oh0 + o0) >> 1) * a.enc_w + ((Cb + ow0 + wcol) >> 1)] = (uint8_t)(v ? 32u - (uint32_t)__clz((int)v) : 0u);
+        }
+    }
     if (a.maxabs != nullptr) {
         block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 
-template <int F, uint32_t LOM, uint32_t HIM>
+template <int F, uint32_t LOM, uint32_t HIM, bool EMIT = false>
 __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
     // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
@@ -209,7 +250,7 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     __shared__ int s_row[NR];
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
-    dwt_tile<F, LOM, HIM, PS, NR>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
+    dwt_tile<F, LOM, HIM, PS, NR, EMIT>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
 }
 
 // ---- helpers of the persistent inverse-transform kernel (k_idwt_level_pf) -------------------------------------------
@@ -1299,7 +1340,7 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     }
 #ifdef SPIHT_DIAG
     static const int use_march = [] { const char *e = getenv("SPIHT_DWT_MARCH"); return e ? atoi(e) : 0; }();
-    if (use_march) {
+    if (use_march && !a.dmsb) {
         constexpr int SW = (256 - (F - 2)) / 2;
         const uint32_t gx = (uint32_t)((a.out_w + SW - 1) / SW), gy = (uint32_t)((a.out_h + MW_ROWS - 1) / MW_ROWS);
         hipLaunchKernelGGL((k_dwt_march<F, LOM, HIM>), dim3(gx * gy * (uint32_t)planes), dim3(256), 0, st, a, gx, gy);
@@ -1315,7 +1356,8 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
     const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
-    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    if (a.dmsb) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
     if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
@@ -1383,6 +1425,18 @@ static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st, TileCtr
     return launch_idwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st, tc);
 }
 
+// What a launch of level 1 with a->dmsb set writes ahead of the pyramid pass (same rule as launch_dwt_FM's ov_h / ov_w).
+extern "C" void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv) {
+    int z = 0;
+    while (z < a->F && a->lo[z] == 0.0 && a->hi[z] == 0.0) z++;
+    int ov_h = a->out_h, ov_w = a->out_w;
+    if (a->mode != 4 && a->in_h >= a->F) ov_h = min(a->out_h, (a->in_h + z + 2) / 2);
+    if (a->mode != 4 && a->in_w >= a->F) ov_w = min(a->out_w, (a->in_w + z + 2) / 2);
+    cv->on = 1;
+    cv->off_h = a->off_h; cv->off_w = a->off_w;
+    cv->lim_h = ov_h; cv->lim_w = ov_w;
+    cv->pad = 0;
+}
 extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st) {
     switch (a->F) {
     case 2: return launch_dwt_F<2, 0x3u, 0x3u>(*a, planes, st);            // haar

@@ -20,6 +20,7 @@
 // `round` d >= 3 handles the nodes of depth exactly d, whose offspring were finished before.
 // HBM-bound: 4 B read per coefficient, ~1/4 + 1/16 B written.
 #include "common.h"
+#include <string.h>
 
 __device__ __forceinline__ uint32_t msb_code(uint32_t v) { return v ? 32u - (uint32_t)__clz((int)v) : 0u; }
 __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 ? -x : x); }
@@ -142,6 +143,11 @@ __global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a, uint32_t gx, uint3
 // Lane pairs exchange their byte results with one cross-lane read each and the even lane stores for both (one 4-byte
 // store per offspring row, 2-byte stores for the pair of q).  Nodes of the root block are left to k_pyr_ll.
 // 1-D grid, XCD-contiguous tile order; tiles: (ceil(cols/64), ceil(rows/4), B*c), block (64,4).
+// COVER: level 1 of the forward transform has written D of the depth-1 nodes whose block lies inside one of its tiles
+// and one detail band already (a.cov, d1_rows_covered / d1_cols_covered): for a row of two such offspring the thread reads their two code
+// bytes instead of the 2x4 coefficients below them, and does not write them again.  A row with an offspring that is
+// not covered is computed from the coefficients as before (always right: the array is final when this kernel runs).
+template <bool COVER>
 __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t gy, uint32_t gz) {
     const Geom g = a.g;
     uint32_t bx, by, bz;
@@ -177,7 +183,50 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
     const bool wq = dom && !((uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w) && !(qi < lh && qj < lw);
     any = any || wq;
     int32_t xc[2][2] = {{0, 0}, {0, 0}}, xg[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (any) {
+    bool cvr[2] = {false, false};   // offspring row rr: both D codes are in memory already
+    uint32_t dcv[2][2] = {{0, 0}, {0, 0}};
+    if (COVER && any && cj + 1 < w) {
+        const int cc0 = d1_cols_covered(a.cov, cj), cc1 = d1_cols_covered(a.cov, cj + 1);
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            // (the offspring of a row are two depth-1 nodes here or none: a covered node's block lies inside the array)
+            const int rc = ci + rr < h ? d1_rows_covered(a.cov, ci + rr) : 0;
+            cvr[rr] = rc && cc0 && cc1 && !(rc == 1 && (cc0 == 1 || cc1 == 1));
+        }
+    }
+    if (COVER && any && (cvr[0] || cvr[1])) {
+        // the offspring's own values always; per offspring row either the two code bytes or the 2x4 values below it
+        const bool inb = gi + 3 < h && gj + 3 < w;
+        if (inb) {
+            const i2u c0 = *reinterpret_cast<const i2u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i2u *>(x + (size_t)(ci + 1) * w + cj);
+            xc[0][0] = c0.v[0]; xc[0][1] = c0.v[1]; xc[1][0] = c1.v[0]; xc[1][1] = c1.v[1];
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int q = 0; q < 2; q++) xc[rr][q] = (ci + rr < h && cj + q < w) ? x[(size_t)(ci + rr) * w + cj + q] : 0;
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            if (cvr[rr]) {
+                const b2u e = *reinterpret_cast<const b2u *>(dm + (size_t)(ci + rr) * w + cj);
+                dcv[rr][0] = e.v[0]; dcv[rr][1] = e.v[1];
+            } else if (inb) {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++) {
+                    const i4u r = *reinterpret_cast<const i4u *>(x + (size_t)(gi + 2 * rr + r2) * w + gj);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) xg[2 * rr + r2][q] = r.v[q];
+                }
+            } else {
+#pragma unroll
+                for (int r2 = 0; r2 < 2; r2++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        xg[2 * rr + r2][q] = (gi + 2 * rr + r2 < h && gj + q < w) ? x[(size_t)(gi + 2 * rr + r2) * w + gj + q] : 0;
+            }
+        }
+    } else if (any) {
         if (gi + 3 < h && gj + 3 < w) {
             const i2u c0 = *reinterpret_cast<const i2u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i2u *>(x + (size_t)(ci + 1) * w + cj);
             i4u r[4];
@@ -209,12 +258,18 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
             uint32_t d = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) d = max(d, msb_code(iabs_u(xg[2 * rr + (u >> 1)][2 * q + (u & 1)])));
+            if (COVER && cvr[rr]) d = dcv[rr][q];
             dch[rr][q] = has ? d : 0u;
             dq = max(dq, max(msb_code(iabs_u(xc[rr][q])), dch[rr][q]));
             lq = max(lq, dch[rr][q]);
         }
     // pack: this lane's bytes | partner's bytes (lanes 2k, 2k+1 own adjacent columns)
     const uint32_t mine0 = dch[0][0] | (dch[0][1] << 8), mine1 = dch[1][0] | (dch[1][1] << 8);
+    if (COVER) {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++)
+            if (cvr[rr]) { wr[rr][0] = false; wr[rr][1] = false; }
+    }
     const uint32_t mflags = (wr[0][0] ? 1u : 0u) | (wr[0][1] ? 2u : 0u) | (wr[1][0] ? 4u : 0u) | (wr[1][1] ? 8u : 0u) | (wq ? 16u : 0u);
     const uint32_t mineq = dq | (lq << 8) | (mflags << 16);
     const uint32_t oth0 = (uint32_t)__shfl_xor((int)mine0, 1), oth1 = (uint32_t)__shfl_xor((int)mine1, 1);
@@ -315,9 +370,12 @@ extern "C" int spiht_pyr_rounds(const Geom *g) {
     return best;
 }
 
+// cov: what level 1 of the forward transform wrote into d_dmsb ahead of this pass (nullptr: nothing)
 extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb,
-                                    hipStream_t st) {
+                                    const D1Cover *cov, hipStream_t st) {
     PyrArgs a;
+    memset(&a.cov, 0, sizeof(a.cov));
+    if (cov) a.cov = *cov;
     a.g = *g;
     a.B = B;
     a.x = d_x;
@@ -331,7 +389,8 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
         if (rows && pairs) {
             const uint32_t cols = 2 * pairs;  // an even number of columns: lane pairs stay together
             const uint32_t gx = (cols + 63) / 64, gy = (rows + 3) / 4, gz = (uint32_t)(B * g->c);
-            hipLaunchKernelGGL(k_pyr_12, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
+            if (a.cov.on) hipLaunchKernelGGL(k_pyr_12<true>, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
+            else hipLaunchKernelGGL(k_pyr_12<false>, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
         }
     }
     for (int d = 3; d <= rounds; d++) {

@@ -16,8 +16,48 @@ import time
 
 import numpy as np
 
-_MAGIC = b"SPIHTID1"
+_MAGIC = b"SPIHTID2"
 _PORT_SPAN = 16  # candidate ports MASTER_PORT+1 .. MASTER_PORT+_PORT_SPAN (MASTER_PORT itself is the launcher's store)
+
+
+def _job_token(addr, base):
+    """8 bytes every rank of ONE job computes alike and another job on the same host does not: two jobs with nearby
+    MASTER_PORTs (29500 / 29501) have overlapping candidate ranges, and a peer must not take the other job's rank 0 for
+    its own -- it would receive a foreign RCCL id and hang in ncclCommInitRank.  From the launcher's rendezvous point,
+    its run id where there is one (torchrun: TORCHELASTIC_RUN_ID) and SPIHT_JOB_TOKEN (set by bench.py's own spawner)."""
+    import hashlib
+    key = "%s:%d|%s|%s" % (addr, base, os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("SPIHT_JOB_TOKEN", ""))
+    return hashlib.sha1(key.encode()).digest()[:8]
+
+
+def _ports(base):
+    """the candidate ports, inside the valid range whatever MASTER_PORT is"""
+    return [p for p in range(base + 1, base + _PORT_SPAN + 1) if 0 < p <= 65535]
+
+
+def _listen(addr, base, backlog, what):
+    """rank 0's listening socket: the first free candidate port, on MASTER_ADDR's interface (rank 0 runs there by the
+    launcher's contract) -- on every interface only if that name is not an address of this host"""
+    import errno
+    hosts = [addr, ""]
+    for p in _ports(base):
+        for host in list(hosts):
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind((host, p))
+                s.listen(backlog)
+                return s
+            except socket.gaierror:   # MASTER_ADDR does not resolve here
+                s.close()
+                hosts = [""]
+            except OSError as e:
+                s.close()
+                if host and e.errno == errno.EADDRNOTAVAIL:  # ... or is not an address of this host
+                    hosts = [""]
+                    continue
+                break  # port taken: the next one
+    raise RuntimeError("no free port in %d..%d for %s" % (base + 1, base + _PORT_SPAN, what))
 
 
 def _recv_exact(sock, n):
@@ -38,22 +78,11 @@ def exchange_id(rank, world, payload=None, addr=None, port=None, timeout=300.0):
         return payload
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
-    hello = _MAGIC + struct.pack("<II", world, 0)
+    token = _job_token(addr, base)
+    hello = _MAGIC + token + struct.pack("<II", world, 0)
     deadline = time.time() + timeout
     if rank == 0:
-        srv = None
-        for k in range(1, _PORT_SPAN + 1):
-            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            try:
-                s.bind(("", base + k))
-                s.listen(world)
-                srv = s
-                break
-            except OSError:
-                s.close()
-        if srv is None:
-            raise RuntimeError("no free port in %d..%d for the id exchange" % (base + 1, base + _PORT_SPAN))
+        srv = _listen(addr, base, world, "the id exchange")
         served = 0
         srv.settimeout(1.0)
         try:
@@ -68,8 +97,8 @@ def exchange_id(rank, world, payload=None, addr=None, port=None, timeout=300.0):
                     conn.settimeout(5.0)
                     try:
                         if _recv_exact(conn, len(hello)) != hello:
-                            continue
-                        conn.sendall(_MAGIC + struct.pack("<I", len(payload)) + payload)
+                            continue  # another job's peer (or anything else): not served
+                        conn.sendall(_MAGIC + token + struct.pack("<I", len(payload)) + payload)
                         served += 1
                     except (OSError, ConnectionError):
                         continue
@@ -77,15 +106,15 @@ def exchange_id(rank, world, payload=None, addr=None, port=None, timeout=300.0):
             srv.close()
         return payload
     while True:
-        for k in range(1, _PORT_SPAN + 1):
+        for p in _ports(base):
             try:
-                with socket.create_connection((addr, base + k), timeout=2.0) as c:
+                with socket.create_connection((addr, p), timeout=2.0) as c:
                     c.settimeout(5.0)
                     c.sendall(hello)
-                    head = _recv_exact(c, len(_MAGIC) + 4)
-                    if head[:len(_MAGIC)] != _MAGIC:
-                        continue
-                    (n,) = struct.unpack("<I", head[len(_MAGIC):])
+                    head = _recv_exact(c, len(_MAGIC) + len(token) + 4)
+                    if head[:len(_MAGIC) + len(token)] != _MAGIC + token:
+                        continue  # another job's rank 0
+                    (n,) = struct.unpack("<I", head[len(_MAGIC) + len(token):])
                     return _recv_exact(c, n)
             except (OSError, ConnectionError):
                 continue
@@ -107,22 +136,11 @@ class HostGroup:
             return
         addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
         base = int(port if port is not None else os.environ.get("MASTER_PORT", "29500"))
-        hello = _MAGIC + struct.pack("<II", self.world, 1)
+        token = _job_token(addr, base)
+        hello = _MAGIC + token + struct.pack("<II", self.world, 1)
         deadline = time.time() + timeout
         if self.rank == 0:
-            srv = None
-            for k in range(1, _PORT_SPAN + 1):
-                s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                try:
-                    s.bind(("", base + k))
-                    s.listen(self.world)
-                    srv = s
-                    break
-                except OSError:
-                    s.close()
-            if srv is None:
-                raise RuntimeError("no free port in %d..%d for the job's host channel" % (base + 1, base + _PORT_SPAN))
+            srv = _listen(addr, base, self.world, "the job's host channel")
             srv.settimeout(1.0)
             try:
                 while len(self.peers) < self.world - 1:
@@ -137,9 +155,9 @@ class HostGroup:
                         head = _recv_exact(conn, len(hello) + 4)
                         (r,) = struct.unpack("<I", head[len(hello):])
                         if head[:len(hello)] != hello or not 0 < r < self.world or r in self.peers:
-                            conn.close()
+                            conn.close()  # (a peer of another job included: its token differs)
                             continue
-                        conn.sendall(_MAGIC)
+                        conn.sendall(_MAGIC + token)
                         conn.settimeout(timeout)
                         conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                         self.peers[r] = conn
@@ -149,12 +167,12 @@ class HostGroup:
                 srv.close()
             return
         while self.sock is None:
-            for k in range(1, _PORT_SPAN + 1):
+            for p in _ports(base):
                 try:
-                    c = socket.create_connection((addr, base + k), timeout=2.0)
+                    c = socket.create_connection((addr, p), timeout=2.0)
                     c.settimeout(5.0)
                     c.sendall(hello + struct.pack("<I", self.rank))
-                    if _recv_exact(c, len(_MAGIC)) != _MAGIC:
+                    if _recv_exact(c, len(_MAGIC) + len(token)) != _MAGIC + token:
                         c.close()
                         continue
                     c.settimeout(timeout)

@@ -49,7 +49,9 @@ def encode(x, ll_h, ll_w, max_bits):
     if x.size == 0:
         raise PanicException("called `Option::unwrap()` on a `None` value")
     es = x.itemsize
-    max_abs = int(np.abs(x.astype(np.int64)).max())
+    # sizes the output buffer only (the device computes max|x| itself, pyramid.hip: k_absmax): two reductions over the
+    # caller's array in place -- no widened copy
+    max_abs = max(-int(x.min()), int(x.max()))
     bound = C.c_uint64()
     _lib.check(L.spiht_encode_bound(c, h, w, ll_h, ll_w, min(max_abs, 0xFFFFFFFF), max_bits, C.byref(bound)))
     out = np.empty(max(int(bound.value), 4), dtype=np.uint8)

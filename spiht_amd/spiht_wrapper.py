@@ -94,11 +94,7 @@ def get_slices_and_h_w(h: int, w: int, spiht_settings: SpihtSettings, level: Opt
     packed coefficient array.  Closed form len' = (len + F - 1)//2 instead of pywt.wavedecn_shapes."""
     wid, _ = _wavelet_mode_ids(spiht_settings)
     g = _geometry(h, w, wid, level)
-    F = _FILTER_LEN[spiht_settings.wavelet]
-    hs, ws = [h], [w]
-    for _ in range(g["level"]):
-        hs.append((hs[-1] + F - 1) // 2)
-        ws.append((ws[-1] + F - 1) // 2)
+    hs, ws = _band_sizes(h, w, spiht_settings.wavelet, g["level"])
     start_h, start_w = hs[-1], ws[-1]
     slices: List[Any] = [(slice(None), slice(start_h), slice(start_w))]
     for lv in range(g["level"], 0, -1):
@@ -212,41 +208,46 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
     return out
 
 
-def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSettings, return_metadata: bool = False):
-    """wrapper:218-257"""
-    encoded_bytes = encoding_result.encoded_bytes
-    h, w, c = encoding_result.h, encoding_result.w, encoding_result.c
-    max_n, level = encoding_result.max_n, encoding_result.level
+def _band_sizes(h, w, wavelet, levels):
+    """band heights / widths per level, [0] = the image: len' = (len + F - 1) // 2 (pywt.dwt_coeff_len, every mode but
+    periodization)"""
+    F = _FILTER_LEN[wavelet]
+    hs, ws = [int(h)], [int(w)]
+    for _ in range(levels):
+        hs.append((hs[-1] + F - 1) // 2)
+        ws.append((ws[-1] + F - 1) // 2)
+    return hs, ws
 
+
+def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSettings, return_metadata: bool = False):
+    """wrapper:218-257: stream -> int32 coefficient array (+ the coder's per-bit metadata)."""
     if encoding_result._encoding_version != ENCODER_DECODER_VERSION:
         raise ValueError(encoding_result._encoding_version)
-
-    slices, enc_h, enc_w = get_slices_and_h_w(h, w, spiht_settings, level)
-    ll_h, ll_w = slices[0][1].stop, slices[0][2].stop
-
-    if return_metadata:
-        # wrapper:232-250.  The reference passes `slice.start` as is, which is None for the 'a' axes of
-        # pywt.coeffs_to_array's slices (and PyO3 then refuses it); `or 0` is what :234-235 does for the top slice.
-        top_slice = [
-            (slices[0][1].start or 0, slices[0][1].stop),
-            (slices[0][2].start or 0, slices[0][2].stop),
-        ]
-        other_slices = []
-        for slice_level in slices[1:]:
-            slice_filters = []
-            for filter_key in ["da", "ad", "dd"]:
-                slice_filter = slice_level[filter_key]
-                slice_filters.append([
-                    (slice_filter[1].start or 0, slice_filter[1].stop),
-                    (slice_filter[2].start or 0, slice_filter[2].stop),
-                ])
-            other_slices.append(slice_filters)
-        rec_arr, spiht_metadata = spiht_rs.decode_with_metadata(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w,
-                                                                top_slice, other_slices)
+    er = encoding_result
+    wid, _ = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(er.h, er.w, wid, er.level)
+    slices, enc_h, enc_w = get_slices_and_h_w(er.h, er.w, spiht_settings, er.level)  # (returned to the caller, as the reference does)
+    spiht_metadata = None
+    if not return_metadata:
+        rec_arr = spiht_rs.decode(er.encoded_bytes, er.max_n, er.c, enc_h, enc_w, g["ll_h"], g["ll_w"])
     else:
-        rec_arr = spiht_rs.decode(encoded_bytes, max_n, c, enc_h, enc_w, ll_h, ll_w)
-        spiht_metadata = None
-    return dict(rec_arr=rec_arr, slices=slices, spiht_metadata=spiht_metadata, h=h, w=w, level=level)
+        # The boxes of the sub-bands inside the packed array, as (start, end) pairs per axis: the root block, then per
+        # level (coarsest first) the filters in the order the reference hands them over, 'da', 'ad', 'dd' (wrapper:240).
+        # (The reference reads them off pywt's slice objects, whose `start` is None on the approximation side -- which
+        # PyO3 refuses, wrapper:242-245; here they come from the band sizes, so every start is a number.)
+        hs, ws = _band_sizes(er.h, er.w, spiht_settings.wavelet, g["level"])
+        top_box = [(0, g["ll_h"]), (0, g["ll_w"])]
+        level_boxes = []
+        row0, col0 = g["ll_h"], g["ll_w"]  # where the detail blocks of the level start
+        for lv in range(g["level"], 0, -1):
+            rows, cols = (row0, row0 + hs[lv]), (col0, col0 + ws[lv])
+            level_boxes.append([[rows, (0, ws[lv])],     # 'da': below the approximation
+                                [(0, hs[lv]), cols],     # 'ad': right of it
+                                [rows, cols]])           # 'dd': diagonal
+            row0, col0 = rows[1], cols[1]
+        rec_arr, spiht_metadata = spiht_rs.decode_with_metadata(er.encoded_bytes, er.max_n, er.c, enc_h, enc_w, g["ll_h"],
+                                                                g["ll_w"], top_box, level_boxes)
+    return dict(rec_arr=rec_arr, slices=slices, spiht_metadata=spiht_metadata, h=er.h, w=er.w, level=er.level)
 
 
 def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settings: SpihtSettings, slices=None):

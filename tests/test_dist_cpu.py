@@ -182,3 +182,49 @@ def test_host_group_barrier_max_bcast():
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, 4.5, 0.0, True) for r in range(world)], res
+
+
+def _job_worker(job, rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["SPIHT_JOB_TOKEN"] = "job%d" % job  # what bench.py's spawner sets; torchrun: TORCHELASTIC_RUN_ID
+        from spiht_amd.dist import HostGroup
+        g = HostGroup(rank, world, addr="127.0.0.1", port=port, timeout=60)
+        b = g.bcast(bytes([job]) * 128 if rank == 0 else None)
+        m = g.max(float(10 * job + rank))
+        g.barrier()
+        g.close()
+        q.put((job, rank, b == bytes([job]) * 128, m))
+    except Exception as e:  # pragma: no cover
+        q.put((job, rank, repr(e), None))
+
+
+def test_two_jobs_with_overlapping_port_ranges_do_not_mix():
+    """Two jobs of the same world size on one host whose MASTER_PORTs are one apart share 15 of their 16 candidate ports:
+    a peer must join ITS job's rank 0 (the hello carries a job token; a foreign rank 0 is skipped), or it would be handed
+    the other job's RCCL id.  Peers start before their rank 0, and job 1's rank 0 listens first -- on the very port job
+    0's peers probe first."""
+    import multiprocessing as mp
+    import time
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    q = ctx.Queue()
+    order = [(0, 1, port), (1, 1, port - 1), (1, 0, port - 1), (0, 0, port)]
+    # job 1 uses MASTER_PORT = port - 1: its rank 0 binds port (= job 0's MASTER_PORT + 0 ... first candidate of job 1)
+    procs = []
+    for job, rank, mp_port in order:
+        p = ctx.Process(target=_job_worker, args=(job, rank, 2, mp_port, q))
+        p.start()
+        procs.append(p)
+        time.sleep(0.3)
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, 0, True, 1.0), (0, 1, True, 1.0), (1, 0, True, 11.0), (1, 1, True, 11.0)], res
+
+
+def test_candidate_ports_stay_in_range():
+    from spiht_amd.dist import _ports
+    assert _ports(29500) == list(range(29501, 29517))
+    assert _ports(65530) == [65531, 65532, 65533, 65534, 65535]
+    assert _ports(65535) == []

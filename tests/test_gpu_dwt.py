@@ -221,3 +221,92 @@ def test_float32_pixels_follow_pywt_single_precision(oracle):
         enc64 = spiht_amd.encode_image(img.astype(np.float64), s, level=cs["level"], max_bits=mb)
         assert enc64.encoded_bytes == oracle.encode_image(img.astype(np.float64), cs["wavelet"], cs["mode"], cs["level"], cs["q"],
                                                           cs["mults"], mb)[0]
+
+
+# (c, H, W, wavelet, mode, level): odd and even band offsets, bands narrower / shorter than a tile, every filter length,
+# the five extension modes, one level (nothing written ahead), cfg2's geometry
+D1_CASES = [(3, 96, 160, "bior2.2", "reflect", 3), (1, 97, 163, "bior2.2", "symmetric", 4), (2, 130, 75, "bior4.4", "periodic", 2),
+            (1, 61, 47, "haar", "zero", 3), (1, 64, 64, "haar", "reflect", 5), (2, 200, 264, "bior6.8", "constant", 3),
+            (1, 70, 90, "bior2.2", "reflect", 1), (1, 333, 517, "bior4.4", "reflect", None),
+            (3, 1080, 1920, "bior2.2", "reflect", 7)]
+
+
+@pytest.mark.parametrize("case", D1_CASES)
+def test_pyramid_codes_written_by_forward_level1(oracle, case):
+    """Level 1 of the forward transform writes the D codes of the 2x2 coefficient blocks it holds (dwt.hip: dwt_tile<..,
+    EMIT>), the pyramid pass reads them and computes the blocks that straddle tiles or bands itself (pyramid.hip:
+    k_pyr_12<true>, common.h: d1_covered).  The result must be the recursion's (encoder_decoder.rs:78-121, evaluated
+    per node by the oracle) at every node with offspring -- and the same as the pyramid pass alone gives."""
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    c, H, W, wavelet, mode, level = case
+    L, ctx, vp = _lib.lib(), _lib.default_context(), C.c_void_p
+    wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
+    lv = -1 if level is None else level
+    v = [C.c_int64() for _ in range(6)]
+    lu = C.c_int()
+    _lib.check(L.spiht_geometry(H, W, wid, lv, C.byref(lu), *[C.byref(t) for t in v]))
+    lh, lw, eh, ew = (t.value for t in v[:4])
+    B = 2
+    n = c * eh * ew
+    imgs = np.stack([synth_image(500 + b, c, H, W) for b in range(B)])
+    imgs[1, :, : H // 2] = 0.25  # a flat half: empty sets (code 0) next to non-empty ones
+    d_img = DeviceArray(ctx, imgs.shape, np.float64)
+    d_img.upload(imgs)
+    co, dm, lm, ma = (DeviceArray(ctx, (B, n), np.int32), DeviceArray(ctx, (B, n), np.uint8), DeviceArray(ctx, (B, n), np.uint8),
+                      DeviceArray(ctx, (B,), np.uint32))
+    ctx.memset(dm.ptr, 0xEE, dm.nbytes)
+    ctx.memset(lm.ptr, 0xEE, lm.nbytes)
+    mults = np.array([1.0, 0.5, 2.0][:c])
+    _lib.check(L.spiht_dwt_pyramid_batch_f64(ctx.handle, vp(d_img.ptr), B, c, H, W, wid, mid, lv, 50.0, vp(mults.ctypes.data),
+                                             vp(co.ptr), vp(dm.ptr), vp(lm.ptr), vp(ma.ptr)))
+    ctx.synchronize()
+    x = co.download().reshape(B, c, eh, ew)
+    d_got, l_got = dm.download().reshape(B, c, eh, ew), lm.download().reshape(B, c, eh, ew)
+    # the pyramid pass on its own over the same coefficients
+    ctx.memset(dm.ptr, 0xEE, dm.nbytes)
+    ctx.memset(lm.ptr, 0xEE, lm.nbytes)
+    _lib.check(L.spiht_pyramid_batch_i32(ctx.handle, vp(co.ptr), B, c, eh, ew, lh, lw, vp(dm.ptr), vp(lm.ptr), vp(None)))
+    ctx.synchronize()
+    d_alone, l_alone = dm.download().reshape(B, c, eh, ew), lm.download().reshape(B, c, eh, ew)
+    I, J = np.arange(eh)[:, None], np.arange(ew)[None, :]
+    b_entry = ((4 * I + 3 < eh) & (4 * J + 3 < ew))[None]
+    for b in range(B):
+        if c * eh * ew <= 400000:
+            d_ref, l_ref, has = oracle.set_codes(x[b], lh, lw)
+        else:  # (the recursion takes minutes at 1080p: there the pass on its own, itself checked against it, is the reference)
+            has = ((2 * I + 1 < eh) & (2 * J + 1 < ew) & ~((I < lh) & (J < lw) & (I % 2 == 0) & (J % 2 == 0)))[None].repeat(c, 0)
+            d_ref, l_ref = d_alone[b], l_alone[b]
+        for name, got, alone, ref, where in (("D", d_got[b], d_alone[b], d_ref, has), ("L", l_got[b], l_alone[b], l_ref, has & b_entry)):
+            bad = np.argwhere((got != ref) & where)
+            assert len(bad) == 0, "%s code differs at %d nodes, first %s: got %d want %d" % (
+                name, len(bad), bad[0], got[tuple(bad[0])], ref[tuple(bad[0])])
+            assert np.array_equal(got[where], alone[where])
+    for a in (d_img, co, dm, lm, ma):
+        a.free()
+
+
+def test_maxabs_small_batch_after_large_batch(oracle):
+    """max|coefficient| of an image is raised by one atomic per workgroup, left out when a cached look at the word shows
+    it holds as much already (dwt.hip: block_raise_max, MAXLOOK 1).  That look must never see a value from BEFORE the
+    word was last zeroed: a large-magnitude batch and then a small-magnitude one go through the same context and the
+    same buffer, several times over; start plane and stream of every image must be the oracle's."""
+    import spiht_amd
+    from spiht_amd import _lib
+    from spiht_amd.batch import BatchCodec
+    c, H, W, B = 1, 192, 256, 6
+    ctx = _lib.default_context()
+    big = np.stack([synth_image(40 + b, c, H, W) * 4000.0 for b in range(B)])
+    small = np.stack([synth_image(60 + b, c, H, W) * 0.02 for b in range(B)])
+    s = spiht_amd.SpihtSettings()
+    codec = BatchCodec(c, H, W, s, 4, 6000, ctx=ctx)
+    want = {}
+    for name, imgs in (("big", big), ("small", small)):
+        want[name] = [oracle.encode_image(imgs[b], "bior2.2", "reflect", 4, 50.0, None, 6000)[:2] for b in range(B)]
+    assert min(w[1] for w in want["big"]) > max(w[1] for w in want["small"]) + 8  # the start planes are far apart
+    for _ in range(4):
+        for name, imgs in (("big", big), ("small", small)):
+            res = codec.encode(imgs)
+            for b in range(B):
+                assert res[b].max_n == want[name][b][1], (name, b)
+                assert res[b].encoded_bytes == want[name][b][0], (name, b)

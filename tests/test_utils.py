@@ -51,3 +51,18 @@ def test_cli_defaults_match_reference():
     assert (a.bpp, a.quantization_scale, a.level, a.wavelet, a.mode, a.color_model, a.per_channel_quant_scales, a.out) == \
         (0.1, 255.0, None, "bior2.2", "reflect", "IPT", "1., 0.2, 0.2", "reconstructed.png")
     assert default_level(1080, 1920) == 7 and default_level(512, 512) == 6 and default_level(64, 4096) == 3
+
+
+def test_reference_import_name():
+    """An unchanged caller of the reference says `import spiht` (reference encode_decode.py:10-14, make_gif.py:9-12,
+    demonstrate.py:10-13): the alias package hands it this repository's modules, the same objects."""
+    import spiht
+    import spiht_amd
+    from spiht import encode_image, decode_image, SpihtSettings, EncodingResult, ENCODER_DECODER_VERSION  # noqa: F401
+    from spiht.spiht_wrapper import get_slices_and_h_w  # noqa: F401
+    from spiht.utils import imload  # noqa: F401
+    from spiht.spiht import decode, encode
+    import spiht.spiht as ext
+    assert ext is spiht_amd.spiht and spiht.spiht is ext
+    assert encode_image is spiht_amd.encode_image and decode is spiht_amd.decode and encode is spiht_amd.encode
+    assert spiht.spiht_wrapper is spiht_amd.spiht_wrapper and SpihtSettings is spiht_amd.SpihtSettings
