@@ -155,10 +155,12 @@ def main():
     ap.add_argument("--pair", choices=["forward", "inverse"], default="inverse",
                     help="what the list decoder of step i shares the GPU with in the pipelined schedule: the forward transform of "
                          "step i+1 or the inverse transform of step i-1 (default; OverlappedCodec)")
-    ap.add_argument("--split-inverse", type=int, default=0, help="experiment: coarse inverse levels on the list-coding stream")
-    ap.add_argument("--l-priority", type=int, default=0, help="experiment: stream priority of the list-coding contexts")
-    ap.add_argument("--e-first", type=int, default=0, help="experiment: encoder kernel queued before the unscatter")
-    ap.add_argument("--u-early", type=int, default=1, help="unscatter right behind the inverse transform (0: in front of the next encoder kernel)")
+    ap.add_argument("--l1-flags", type=int, default=1,
+                    help="1 (default): the list decoder flags the occupied level-1 tiles and the inverse transform does not read the "
+                         "detail bands of the others (include/spiht_hip.h: spiht_decode_lists_flags_batch_i32); 0: reads everything")
+    ap.add_argument("--d1-emit", type=int, default=0,
+                    help="1: level 1 of the forward transform writes pyramid codes ahead of the pyramid pass (measured, not the "
+                         "default: DESIGN.md 6)")
     ap.add_argument("--decoder-waves", type=int, default=8, choices=[8, 12],
                     help="wavefronts per decoder workgroup in the pipelined schedule (12: the library's default for single calls)")
     ap.add_argument("--streams", type=int, default=1,
@@ -198,6 +200,8 @@ def main():
     from spiht_amd.spiht_wrapper import SpihtSettings
 
     ctx = _lib.default_context(local_rank)
+    ctx.set_option("l1_flags", args.l1_flags)
+    ctx.set_option("d1_emit", args.d1_emit)
     comm = group = None
     comm_error = None
     if use_comm:
@@ -221,6 +225,9 @@ def main():
     max_bits = int(H * W * BPP)  # demonstrate.py:50
     K = max(1, min(args.streams, B))
     ctxs = [ctx] + [_lib.Context(local_rank) for _ in range(K - 1)]
+    for cx in ctxs[1:]:
+        cx.set_option("l1_flags", args.l1_flags)
+        cx.set_option("d1_emit", args.d1_emit)
     settings = SpihtSettings(WAVELET, QSCALE, MODE)
     codecs = [BatchCodec(C_IMG, H, W, settings, LEVEL, max_bits, ctx=cx, pixel_dtype=pix) for cx in ctxs]
     codec = codecs[0]
@@ -275,8 +282,7 @@ def main():
         # list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).  The
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
         from spiht_amd.batch import OverlappedCodec
-        pipe = OverlappedCodec(codec, B, pair=args.pair, split_inverse=bool(args.split_inverse), l_priority=args.l_priority,
-                               e_first=bool(args.e_first), u_early=bool(args.u_early), decoder_waves=args.decoder_waves)
+        pipe = OverlappedCodec(codec, B, pair=args.pair, decoder_waves=args.decoder_waves, l1_flags=bool(args.l1_flags))
         ctxs.extend(pipe.Ls)
 
     def step():

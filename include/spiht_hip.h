@@ -222,6 +222,29 @@ int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t
                                  const uint8_t *d_max_n, int64_t B, int64_t c, int64_t h, int64_t w, int64_t ll_h,
                                  int64_t ll_w, int32_t *d_out_zeroed);
 int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, int64_t c, int64_t h, int64_t w);
+/* Occupancy of the inverse transform's level-1 tiles, handed from the list decoder to the inverse transform.  The
+ * reference's decoder fills a dense array and waverec2 reads all of it (spiht_wrapper.py:248-276); at the metric's bit
+ * rates nearly every cell of the level-1 detail bands -- three quarters of the array -- is zero, and the decoder knows
+ * every cell it writes: it sets one 32-bit word per (plane, inverse-transform tile) whose staged band region holds a
+ * decoded cell, and level 1 of the inverse transform does not read the detail bands of a tile whose word is zero (zeros go
+ * through the same arithmetic: the same bits).  The image-level decode calls do this internally (option "l1_flags");
+ * the split calls take the words explicitly:
+ *   spiht_l1_flags_words                 words per image for this geometry (0: not applicable -- fewer than two levels)
+ *   spiht_decode_lists_flags_batch_i32   spiht_decode_lists_batch_i32 for the arrays of H x W images + the words
+ *                                        (zero-filled by the call; d_flags NULL: no flags)
+ *   spiht_dequant_idwt_flags_batch_f64   spiht_dequant_idwt_batch_f64 reading them (d_flags NULL: reads everything) */
+int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int level, uint64_t *words_per_image);
+int spiht_decode_lists_flags_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
+                                       const uint8_t *d_max_n, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet,
+                                       int level, int32_t *d_out_zeroed, uint32_t *d_flags);
+int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const uint32_t *d_flags, int64_t B, int64_t c,
+                                       int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                       const double *channel_mults, double *d_img_out);
+/* Switches of this library's own making; the results are the same bits whatever they are set to.  "d1_emit" (default 0):
+ * level 1 of the forward transform writes significance-pyramid codes ahead of the pyramid pass; "l1_flags" (default 1):
+ * the occupancy words above inside the image-level decode calls.  value 0 / 1. */
+int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
+
 /* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels
  * (level .. 2: a quarter of the bytes) into d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] float64 -- the approximation level 1
  * starts from; spiht_idwt_approx_shape gives its size -- and level 1 from d_rec + d_approx to the pixels.  With fewer than

@@ -48,6 +48,7 @@ SYMBOLS = [
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
+    "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
 ]
 
 
@@ -140,6 +141,10 @@ def lib():
         L.spiht_comm_allreduce_max_f64.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.spiht_rccl_library.restype = C.c_char_p
         L.spiht_rccl_library.argtypes = []
+        L.spiht_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.spiht_l1_flags_words.argtypes = [i64, i64, i64, i32, i32, C.POINTER(u64)]
+        L.spiht_decode_lists_flags_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, vp, vp]
+        L.spiht_dequant_idwt_flags_batch_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
         L.spiht_ctx_lock.argtypes = [vp]
         L.spiht_ctx_unlock.argtypes = [vp]
         _lib = L
@@ -191,6 +196,10 @@ class Context:
 
     def unlock(self):
         check(self._lib.spiht_ctx_unlock(self.handle))
+
+    def set_option(self, name, value):
+        """a switch of the library (spiht_ctx_set_option): "d1_emit", "l1_flags"; results do not depend on them"""
+        check(self._lib.spiht_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def set_decoder_waves(self, waves):
         """wavefronts per decoder workgroup on this context: 12 (default, fastest alone) or 8 (lighter beside HBM-bound

@@ -226,7 +226,7 @@ class OverlappedCodec:
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
     def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=True,
-                 decoder_waves=8):
+                 decoder_waves=8, l1_flags=True):
         self.codec, self.B = codec, int(B)
         if pair not in ("forward", "inverse"):
             raise ValueError("pair must be 'forward' or 'inverse'")
@@ -253,6 +253,10 @@ class OverlappedCodec:
         _lib.check(codec.L.spiht_idwt_approx_shape(codec.H, codec.W, codec.wid, codec._lv, C.byref(ah), C.byref(aw)))
         self.split = ah.value > 0 and split_inverse  # two levels or more: coarse levels on the list-coding stream
         self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if self.split else [None, None]
+        # occupancy words of the inverse transform's level-1 tiles: decoder -> inverse transform (include/spiht_hip.h)
+        nw = C.c_uint64()
+        _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec._lv, C.byref(nw)))
+        self.flags = mk((B, nw.value), np.uint32) if nw.value and l1_flags else [None, None]
         for r in self.rec:  # zero once; from then on U keeps them zero
             self.H.memset(r.ptr, 0, r.nbytes)
         self.H.synchronize()
@@ -275,9 +279,10 @@ class OverlappedCodec:
                     self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr), self.B, cd.c, cd.H, cd.W,
                     cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
             else:
-                _lib.check(cd.L.spiht_dequant_idwt_batch_f64(
-                    self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
-                    float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
+                _lib.check(cd.L.spiht_dequant_idwt_flags_batch_f64(
+                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.flags[s].ptr if self.flags[s] else None), self.B,
+                    cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p,
+                    C.c_void_p(d_img_out)))
         self.H.record(self.ev_i[s])
 
     def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None, dec_src=None):
@@ -325,9 +330,9 @@ class OverlappedCodec:
             self._pending = None
         x_out, x_nbits, x_max_n = dec_src if dec_src is not None else (d_out, d_nbits, d_max_n)
         _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(x_nbits), B, vp(d_nbytes)))
-        _lib.check(cd.L.spiht_decode_lists_batch_i32(
-            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, g["enc_h"], g["enc_w"],
-            g["ll_h"], g["ll_w"], vp(self.rec[s].ptr)))
+        _lib.check(cd.L.spiht_decode_lists_flags_batch_i32(
+            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, cd.H, cd.W, cd.wid, cd._lv,
+            vp(self.rec[s].ptr), vp(self.flags[s].ptr if self.flags[s] else None)))
         if self.split:  # the coarse levels of this batch's inverse transform, behind its decoder
             _lib.check(cd.L.spiht_idwt_coarse_batch_f64(
                 Lc.handle, vp(self.rec[s].ptr), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,

@@ -95,6 +95,10 @@ struct spiht_ctx {
     bool color_on = false;
     Color3 col_fwd, col_inv;
     int dec_waves = 12;  // wavefronts per decoder workgroup (spiht_ctx_set_decoder_waves)
+    // spiht_ctx_set_option
+    bool opt_d1_emit = false;   // level 1 of the forward transform writes pyramid codes ahead of the pyramid pass
+    bool opt_l1_flags = true;   // the decoder flags the occupied level-1 tiles for the inverse transform
+    DevBuf l1flags;             // L1Flags words of the fused decode path
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -389,7 +393,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
+    DevBuf *bufs[] = {&ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
                       &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
@@ -581,7 +585,7 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
 static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, uint64_t slot_stride,
                          const uint64_t *d_nbytes, const uint8_t *d_maxn, int B, int32_t *d_out,
                          uint32_t *d_tr_ent = nullptr, uint8_t *d_tr_act = nullptr, uint64_t tr_stride = 0,
-                         bool zero_out = true, DecArgs *args_out = nullptr) {
+                         bool zero_out = true, DecArgs *args_out = nullptr, const L1Flags *fl = nullptr) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if (slot_stride * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
     ListCaps caps;
@@ -608,6 +612,10 @@ static int decode_device(spiht_ctx *ctx, const Geom &g, const uint8_t *d_data, u
     a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
     a.err = (uint32_t *)ctx->err.p;
     a.tr_ent = d_tr_ent; a.tr_act = d_tr_act; a.tr_stride = tr_stride;
+    if (fl && fl->p) {  // (zero-filled here: the decoder only ever sets words)
+        a.fl = *fl;
+        HIPCHK(hipMemsetAsync(fl->p, 0, (size_t)B * g.c * fl->gy * fl->gx * 4, ctx->stream));
+    }
     if (args_out) {  // the caller wants to undo the scatter later: one LSP length per slot
         CHK(ensure(ctx, ctx->lspcnt, (size_t)nslots * 4));
         a.lsp_count = (uint32_t *)ctx->lspcnt.p;
@@ -1020,7 +1028,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
                        double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false,
                        uint8_t *d_dmsb = nullptr, D1Cover *cov = nullptr) {
     if (cov) memset(cov, 0, sizeof(*cov));
-    static const bool emit_on = [] { const char *e = getenv("SPIHT_D1_EMIT"); return e ? atoi(e) != 0 : true; }();
+    const bool emit_on = ctx->opt_d1_emit;
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
     if (f32) {
@@ -1091,8 +1099,23 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
 // l_hi .. l_lo: the levels to run, coarsest first (ig.L .. 1 = all).  A run that stops above level 1 leaves its last
 // approximation in d_out ([planes, 2*hs[l_lo]-F+2, 2*ws[l_lo]-F+2]); a run that starts below ig.L takes that array as
 // d_a_in.
+// Geometry of the L1Flags words of an image geometry (common.h): false when they do not apply (fewer than two levels: the
+// level-1 approximation then comes out of the packed array too; a filter whose halo exceeds a tile)
+static bool l1flags_geometry(const ImgGeom &ig, int F, L1Flags *fl) {
+    memset(fl, 0, sizeof(*fl));
+    if (ig.L < 2 || F / 2 - 1 > IW_TH / 2 || F / 2 - 1 > IW_TW / 2) return false;
+    fl->off_h = (int32_t)ig.offh[1]; fl->off_w = (int32_t)ig.offw[1];
+    fl->band_h = (int32_t)ig.hs[1]; fl->band_w = (int32_t)ig.ws[1];
+    fl->hf1 = F / 2 - 1;
+    fl->gx = (int32_t)((2 * ig.ws[1] - F + 2 + IW_TW - 1) / IW_TW);
+    fl->gy = (int32_t)((2 * ig.hs[1] - F + 2 + IW_TH - 1) / IW_TH);
+    return fl->gx > 0 && fl->gy > 0;
+}
+
+// d_flags: L1Flags words [planes, gy, gx] the decoder of d_rec left (nullptr: every level-1 tile reads its detail bands)
 static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, const ImgGeom &ig, int wavelet, double q,
-                       const double *d_mults, double *d_out, int l_hi = -1, int l_lo = 1, const double *d_a_in = nullptr) {
+                       const double *d_mults, double *d_out, int l_hi = -1, int l_lo = 1, const double *d_a_in = nullptr,
+                       const uint32_t *d_flags = nullptr) {
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const int F = wv.F;
     if (l_hi < 0) l_hi = ig.L;
@@ -1134,6 +1157,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         a.mults = d_mults;
         a.q = q;
         if (color && l == 1) { a.color = 1; a.col = ctx->col_inv; }
+        if (l == 1 && !a.first && !a.color) a.flags = d_flags;
         memcpy(a.lo, wv.rec_lo, sizeof(double) * F);
         memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
         {
@@ -1186,9 +1210,9 @@ extern "C" int spiht_dwt_quant_batch_f32(spiht_ctx *ctx, const float *d_img, int
     return dwt_quant_batch(ctx, d_img, true, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, d_coeffs);
 }
 
-extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H,
-                                            int64_t W, int wavelet, int mode, int level, double q_scale,
-                                            const double *channel_mults, double *d_img_out) {
+static int dequant_idwt_batch(spiht_ctx *ctx, const int32_t *d_rec, const uint32_t *d_flags, int64_t B, int64_t c, int64_t H,
+                              int64_t W, int wavelet, int mode, int level, double q_scale, const double *channel_mults,
+                              double *d_img_out) {
     if (!ctx || !d_rec || !d_img_out) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
@@ -1199,12 +1223,25 @@ extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec
     const double *d_mults;
     CHK(upload_mults(ctx, channel_mults, c, &d_mults));
     const int chunk = (int)std::max<int64_t>(1, 65535 / c);
+    L1Flags fl;
+    const bool flagged = d_flags && !(ctx->color_on && c == 3) && l1flags_geometry(ig, SPIHT_WAVELETS[wavelet].F, &fl);
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         CHK(dwt_inverse(ctx, d_rec + (size_t)b0 * c * ig.enc_h * ig.enc_w, nb * (int)c, (int)c, ig, wavelet, q_scale,
-                        d_mults, d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+                        d_mults, d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, -1, 1, nullptr,
+                        flagged ? d_flags + (size_t)b0 * c * fl.gy * fl.gx : nullptr));
     }
     return SPIHT_OK;
+}
+extern "C" int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B, int64_t c, int64_t H,
+                                            int64_t W, int wavelet, int mode, int level, double q_scale,
+                                            const double *channel_mults, double *d_img_out) {
+    return dequant_idwt_batch(ctx, d_rec, nullptr, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, d_img_out);
+}
+extern "C" int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const uint32_t *d_flags, int64_t B,
+                                                  int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level,
+                                                  double q_scale, const double *channel_mults, double *d_img_out) {
+    return dequant_idwt_batch(ctx, d_rec, d_flags, B, c, H, W, wavelet, mode, level, q_scale, channel_mults, d_img_out);
 }
 
 // The inverse transform in two parts, so that a pipelined caller can queue the coarse levels (a quarter of the bytes,
@@ -1336,10 +1373,18 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         int32_t *rec = d_rec ? d_rec + (size_t)b0 * g.n : nullptr;
+        // the decoder tells the inverse transform which level-1 tiles hold anything (common.h: L1Flags)
+        L1Flags fl;
+        const bool flagged = ctx->opt_l1_flags && !(ctx->color_on && c == 3) && l1flags_geometry(ig, SPIHT_WAVELETS[wavelet].F, &fl);
+        if (flagged) {
+            CHK(ensure(ctx, ctx->l1flags, (size_t)nb * c * fl.gy * fl.gx * 4));
+            fl.p = (uint32_t *)ctx->l1flags.p;
+        }
         if (rec) {
-            CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec));
+            CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec,
+                              nullptr, nullptr, 0, true, nullptr, flagged ? &fl : nullptr));
             CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
-                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, -1, 1, nullptr, flagged ? fl.p : nullptr));
             continue;
         }
         // Internal coefficient array: it is all zero on entry and is left all zero -- after the inverse transform the
@@ -1355,9 +1400,9 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
         rec = (int32_t *)ctx->recz.p;
         DecArgs da;
         CHK(decode_device(ctx, g, d_data + (size_t)b0 * slot_stride, slot_stride, d_nbytes + b0, d_max_n + b0, nb, rec, nullptr,
-                          nullptr, 0, false, &da));
+                          nullptr, 0, false, &da, flagged ? &fl : nullptr));
         CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
-                        d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W));
+                        d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, -1, 1, nullptr, flagged ? fl.p : nullptr));
         if (da.nslots >= nb) {
             StageTimer t(ctx, ST_MEMSET);
             LAUNCHCHK(spiht_launch_unscatter(&da, ctx->stream));
@@ -1560,20 +1605,42 @@ extern "C" int spiht_encode_lists_batch_i32(spiht_ctx *ctx, const int32_t *d_x, 
     return SPIHT_OK;
 }
 
+static int decode_lists_batch(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
+                              const uint8_t *d_max_n, int64_t B, const Geom &g, int32_t *d_out_zeroed, const L1Flags *fl) {
+    if (B == 0) return SPIHT_OK;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    DecArgs da;
+    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false, &da, fl));
+    ctx->last_dec = da;
+    ctx->last_dec_valid = da.nslots >= (int)B;  // otherwise slots were reused inside the launch
+    return SPIHT_OK;
+}
 extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
                                             const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c,
                                             int64_t h, int64_t w, int64_t ll_h, int64_t ll_w, int32_t *d_out_zeroed) {
     if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_out_zeroed || B < 0) return SPIHT_ERR_ARG;
     Geom g;
     CHK(make_geom(c, h, w, ll_h, ll_w, &g));
-    if (B == 0) return SPIHT_OK;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    HIPCHK(hipSetDevice(ctx->device));
-    DecArgs da;
-    CHK(decode_device(ctx, g, d_data, slot_stride, d_nbytes, d_max_n, (int)B, d_out_zeroed, nullptr, nullptr, 0, false, &da));
-    ctx->last_dec = da;
-    ctx->last_dec_valid = da.nslots >= (int)B;  // otherwise slots were reused inside the launch
-    return SPIHT_OK;
+    return decode_lists_batch(ctx, d_data, slot_stride, d_nbytes, d_max_n, B, g, d_out_zeroed, nullptr);
+}
+// The same for the coefficient arrays of B images of H x W pixels (the geometry spiht_geometry gives), leaving in d_flags
+// (spiht_l1_flags_words(...) x B words; zero-filled by this call) the occupancy of the inverse transform's level-1 tiles
+// for spiht_dequant_idwt_flags_batch_f64.  d_flags == NULL or a geometry without flags: as spiht_decode_lists_batch_i32.
+extern "C" int spiht_decode_lists_flags_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
+                                                  const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c,
+                                                  int64_t H, int64_t W, int wavelet, int level, int32_t *d_out_zeroed,
+                                                  uint32_t *d_flags) {
+    if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_out_zeroed || B < 0) return SPIHT_ERR_ARG;
+    CHK(check_img_args(wavelet, 0, B, c, H, W));
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    Geom g;
+    CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
+    L1Flags fl;
+    const bool flagged = d_flags && l1flags_geometry(ig, SPIHT_WAVELETS[wavelet].F, &fl);
+    if (flagged) fl.p = d_flags;
+    return decode_lists_batch(ctx, d_data, slot_stride, d_nbytes, d_max_n, B, g, d_out_zeroed, flagged ? &fl : nullptr);
 }
 
 // Puts the zeros back into the array the context's last spiht_decode_lists_batch_i32 scattered into (after its
@@ -1611,6 +1678,30 @@ extern "C" int spiht_ctx_lock(spiht_ctx *ctx) {
 extern "C" int spiht_ctx_unlock(spiht_ctx *ctx) {
     if (!ctx) return SPIHT_ERR_ARG;
     ctx->mu.unlock();
+    return SPIHT_OK;
+}
+
+// Switches of this library's own making (nothing of the reference): "d1_emit" (default 0) level 1 of the forward
+// transform writes significance-pyramid codes ahead of the pyramid pass (measured, not the default);
+// "l1_flags" (default 1) the list decoder flags the occupied level-1 tiles for the inverse transform of the image-level
+// decode calls.  Results are the same bits whatever the setting.  Unknown name / value: SPIHT_ERR_ARG.
+extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name || (value != 0 && value != 1)) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!strcmp(name, "d1_emit")) ctx->opt_d1_emit = value != 0;
+    else if (!strcmp(name, "l1_flags")) ctx->opt_l1_flags = value != 0;
+    else return SPIHT_ERR_ARG;
+    return SPIHT_OK;
+}
+
+// Size, in 32-bit words per image, of the occupancy words the decoder leaves for the inverse transform's level 1
+// (common.h: L1Flags): 0 when they do not apply to this geometry (fewer than two levels).
+extern "C" int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int level, uint64_t *words_per_image) {
+    if (!words_per_image || wavelet < 0 || wavelet >= SPIHT_NWAVELETS || c < 1) return SPIHT_ERR_ARG;
+    ImgGeom ig;
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    L1Flags fl;
+    *words_per_image = l1flags_geometry(ig, SPIHT_WAVELETS[wavelet].F, &fl) ? (uint64_t)c * fl.gy * fl.gx : 0;
     return SPIHT_OK;
 }
 

@@ -74,6 +74,24 @@ struct EncArgs {
     float log2_thresh[32];   // log2_thresh[k]: smallest float m < 2^k with (u8)log2f(m) == k (host libm), or 2^k
 };
 
+// Tile of the inverse level-1 kernels (dwt.hip), in output positions; in band positions half of it.
+#define IW_TH 24    // output rows per tile (two halves, one per half of the workgroup; a multiple of 4)
+#define IW_TW 128   // output cols per tile, one thread per column per half
+
+// Which tiles of the inverse transform's level 1 have anything but zeros in their detail bands: the list decoder knows
+// every cell it writes, so it sets one word per (plane, tile) whose staged band region -- the tile's IW_TH/2 x IW_TW/2
+// band positions plus the halo of F/2 - 1 rows / columns behind them -- contains a decoded cell of a level-1 band; the
+// inverse level-1 kernel then does not read the three int32 detail bands of a tile whose word is still zero (at 0.5 bpp
+// nearly all of them).  Conservative by construction: a set word only means "read".  p == nullptr: no flags.
+struct L1Flags {
+    uint32_t *p;              // [planes, gy, gx] (planes = B*c of the launch), zero-filled before the decoder runs
+    int32_t off_h, off_w;     // offsets of the level-1 detail bands in the packed array
+    int32_t band_h, band_w;   // their size
+    int32_t hf1;              // F/2 - 1: band rows / columns of halo a tile stages beyond its own
+    int32_t gx, gy;           // tiles per plane
+    int32_t pad;
+};
+
 struct DecArgs {
     Geom g;
     ListCaps caps;
@@ -88,6 +106,7 @@ struct DecArgs {
     int32_t *lsp_val;
     uint32_t *err;
     uint32_t *lsp_count;      // [nslots] or null: final LSP length of the image a slot decoded (k_unscatter)
+    L1Flags fl;               // occupancy of the inverse transform's level-1 tiles (fl.p null: not wanted)
     // decode_with_metadata only (k_decode<true>): one trace record per stream position 0..nbits (the last one is
     // the operation that was waiting for a bit when the stream ended)
     uint32_t *tr_ent;         // [B, tr_stride]  entry: node index | filter << 28 (| ENT_A / ENT_LEAF, ignored)
@@ -216,6 +235,7 @@ struct IdwtKArgs {
     int32_t planes;            // B*c (set by the launcher)
     const double *a_in;        // [planes, a_h, a_w]
     const int32_t *rec;        // [planes, enc_h, enc_w]
+    const uint32_t *flags;     // [planes, gy, gx] or null: L1Flags words of this level's tiles (level 1 only)
     double *out;               // [planes, out_h, out_w]
     const double *mults;
     double q;

@@ -398,6 +398,27 @@ __device__ __forceinline__ void tr_put(const Trace &tr, uint32_t pos, uint32_t a
     }
 }
 
+// ---- occupancy of the inverse transform's level-1 tiles (common.h: L1Flags) ----
+// The cell idx of the image's coefficient array gets a value: if it is a cell of a level-1 detail band, the words of the
+// inverse-transform tiles that stage it are set (the tile it lies in and, within F/2 - 1 band rows / columns of that
+// tile's start, the tile before: a tile stages its halo behind itself).  Plain stores of 1: racing writers agree.
+__device__ __forceinline__ void l1_mark(const Geom &g, const L1Flags &f, uint32_t plane0, uint32_t idx) {
+    uint32_t k, i, j;
+    decomp(g, idx, k, i, j);
+    if ((int)i < f.off_h && (int)j < f.off_w) return;  // a coarser level or the root block
+    const uint32_t bi = (int)i >= f.off_h ? i - (uint32_t)f.off_h : i, bj = (int)j >= f.off_w ? j - (uint32_t)f.off_w : j;
+    if (bi >= (uint32_t)f.band_h || bj >= (uint32_t)f.band_w) return;  // a padding cell: the transform never reads it
+    constexpr uint32_t TR = IW_TH / 2, TC = IW_TW / 2;
+    const uint32_t ty = bi / TR, tx = bj / TC;
+    const bool up = bi - ty * TR < (uint32_t)f.hf1 && ty > 0, lf = bj - tx * TC < (uint32_t)f.hf1 && tx > 0;
+    const uint32_t gx = (uint32_t)f.gx, gy = (uint32_t)f.gy;
+    uint32_t *p = f.p + (size_t)(plane0 + k) * gy * gx;
+    if (ty < gy && tx < gx) p[ty * gx + tx] = 1u;
+    if (up && ty - 1u < gy && tx < gx) p[(ty - 1u) * gx + tx] = 1u;
+    if (lf && ty < gy && tx - 1u < gx) p[ty * gx + tx - 1u] = 1u;
+    if (up && lf && ty - 1u < gy && tx - 1u < gx) p[(ty - 1u) * gx + tx - 1u] = 1u;
+}
+
 // ---- duplicated cells ----
 // get_offspring (encoder_decoder.rs:43-75) maps root (i,j) to the 2x2 block at rows (i&1)*ll_h + (i&~1) .. +1, columns
 // likewise.  With an odd ll_h the blocks of the even roots reach row ll_h, where the blocks of the odd roots start:
@@ -1289,10 +1310,15 @@ void k_decode(DecArgs a) {
                     v[u] = t < t_end ? lv : 0;  // a decoded value is never 0
                 }
             };
+            const bool mark = !META && a.fl.p != nullptr;
+            const uint32_t plane0 = (uint32_t)b * (uint32_t)g.c;
             auto st = [&](const int32_t(&v)[U], const uint32_t(&ix)[U]) {
 #pragma unroll
-                for (uint32_t u = 0; u < U; u++)
+                for (uint32_t u = 0; u < U; u++) {
                     if (v[u] && !(dups && dup_cell(g, ix[u] & IDXM))) out[ix[u] & IDXM] = v[u];
+                    // (every entry with a value, those of duplicated cells included: a set word only means "read")
+                    if (mark && v[u]) l1_mark(g, a.fl, plane0, ix[u] & IDXM);
+                }
             };
             if (t_end > 0) {
                 uint32_t t0 = threadIdx.x;

@@ -857,12 +857,9 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // ------------------------------------------------------------------------------------------------
 // inverse
 // ------------------------------------------------------------------------------------------------
-#ifndef IW_TH
-#define IW_TH 24    // output rows per tile (two halves, one per half of the workgroup; a multiple of 4).  Level 1 of 256
-#endif              // 1080p images, workgroup per tile: 16 rows 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67,
-                    // 8: 4.74; persistent kernel beside the list decoder (the pipelined schedule): 16 rows 7.3 ms, 20: 7.0,
-                    // 24: 6.5-6.7, 28: 8.1, 32: 7.6
-#define IW_TW 128   // output cols per tile, one thread per column per half
+// IW_TH x IW_TW (common.h): output rows / columns per tile.  Level 1 of 256 1080p images, workgroup per tile: 16 rows
+// 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67, 8: 4.74; persistent kernel beside the list decoder (the
+// pipelined schedule): 16 rows 7.3 ms, 20: 7.0, 24: 6.5-6.7, 28: 8.1, 32: 7.6
 
 __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
     double v = (double)r;
@@ -892,6 +889,10 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
     const int32_t *__restrict__ rec = a.rec + (size_t)plane * a.enc_h * a.enc_w;
     const double *__restrict__ ain = a.first ? nullptr : a.a_in + (size_t)plane * a.a_h * a.a_w;
     const int tid = threadIdx.x;
+    // L1Flags word of this tile still zero: the decoder wrote nothing into the detail bands it stages -- they are not
+    // read (a zero goes through the same arithmetic: same bits)
+    const bool occupied = a.flags == nullptr ||
+        a.flags[((size_t)plane * ((a.out_h + IW_TH - 1) / IW_TH) + tby) * ((a.out_w + IW_TW - 1) / IW_TW) + tbx] != 0u;
 
     for (int p = tid; p < KH * KW; p += DW_BLOCK) {
         const int r = p / KW, cidx = p - r * KW;
@@ -904,9 +905,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
             const int32_t rda = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
             const int32_t rdd = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
 #else
-            const int32_t rad = rec[(size_t)bi * a.enc_w + a.off_w + bj];
-            const int32_t rda = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
-            const int32_t rdd = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            const int32_t rad = occupied ? rec[(size_t)bi * a.enc_w + a.off_w + bj] : 0;
+            const int32_t rda = occupied ? rec[(size_t)(a.off_h + bi) * a.enc_w + bj] : 0;
+            const int32_t rdd = occupied ? rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj] : 0;
 #endif
             if (a.first) {
                 const int32_t raa = rec[(size_t)bi * a.enc_w + bj];
@@ -1011,9 +1012,14 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 #else
 #define IWP_ATTR
 #endif
-template <int F, uint32_t LOM, uint32_t HIM, bool FIRST>  // FIRST: coarsest level, the approximation comes from the packed array
+// FLAGS: a.flags holds one word per tile (common.h: L1Flags); the detail bands of a tile whose word is zero are all zero
+// and are not read.  The loads stay unconditional -- a branch around them would make every later wait a wait for
+// everything -- and go through a buffer descriptor of the plane instead: an offset beyond it returns 0 without a trip
+// to memory.  The word of a tile is fetched when the tile's number becomes known, a tile of work ahead of its use.
+template <int F, uint32_t LOM, uint32_t HIM, bool FIRST, bool FLAGS = false>  // FIRST: coarsest level, the approximation comes from the packed array
 __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr,
                                                                       TileBase cb) {
+    static_assert(!(FIRST && FLAGS), "the flags are those of level 1 of a transform with two levels or more");
     constexpr int HF = F / 2;
     constexpr int KH = IW_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IW_TH / 4 + HF - 1;
     constexpr int NE = (KH * KW + DW_BLOCK - 1) / DW_BLOCK;  // staged elements per thread
@@ -1053,11 +1059,12 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
         double vaa[NE];
         double mk;  // the plane's channel scale (a load as well: it must not be waited for on its own)
     };
-    auto request = [&](Stage &g, uint32_t T) {  // the loads of tile T (nothing waits for them here)
+    auto request = [&](Stage &g, uint32_t T, uint32_t occ) {  // the loads of tile T (nothing waits for them here)
         const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
         const int kh0 = (int)(by * IW_TH) / 2, kw0 = (int)(bx * IW_TW) / 2;
         const int32_t *__restrict__ rec = a.rec + (size_t)plane * a.enc_h * a.enc_w;
         const double *__restrict__ ain = FIRST ? nullptr : a.a_in + (size_t)plane * a.a_h * a.a_w;
+        const __amdgpu_buffer_rsrc_t rrsrc = plane_rsrc(rec, (uint32_t)a.enc_h * (uint32_t)a.enc_w * 4u);  // (FLAGS only)
         // unconditional loads from clamped positions (a branch around a load makes the compiler wait for it at the
         // join); what lies outside the band is zeroed when the samples go to LDS
 #pragma unroll
@@ -1065,9 +1072,17 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
             const int p = min(tid + e * DW_BLOCK, KH * KW - 1);
             const int rr = p / KW, cidx = p - rr * KW;
             const int bi = min(kh0 + rr, a.band_h - 1), bj = min(kw0 + cidx, a.band_w - 1);
-            g.rad[e] = rec[(size_t)bi * a.enc_w + a.off_w + bj];
-            g.rda[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
-            g.rdd[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            if (FLAGS) {
+                const uint32_t o_ad = ((uint32_t)bi * (uint32_t)a.enc_w + (uint32_t)(a.off_w + bj)) * 4u;
+                const uint32_t o_da = ((uint32_t)(a.off_h + bi) * (uint32_t)a.enc_w + (uint32_t)bj) * 4u;
+                g.rad[e] = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, occ ? o_ad : BUF_OOB, 0, 0);
+                g.rda[e] = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, occ ? o_da : BUF_OOB, 0, 0);
+                g.rdd[e] = __builtin_amdgcn_raw_buffer_load_b32(rrsrc, occ ? o_da + (uint32_t)a.off_w * 4u : BUF_OOB, 0, 0);
+            } else {
+                g.rad[e] = rec[(size_t)bi * a.enc_w + a.off_w + bj];
+                g.rda[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
+                g.rdd[e] = rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
+            }
             if (FIRST) { g.raa[e] = rec[(size_t)bi * a.enc_w + bj]; g.vaa[e] = 0.0; }
             else { g.vaa[e] = ain[(size_t)bi * a.a_w + bj]; g.raa[e] = 0; }
         }
@@ -1083,7 +1098,7 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     }
     const bool has_m = a.mults != nullptr;
     // one tile: its samples (in g) -> LDS, then g is free and takes the loads of the next tile; filter; store
-    auto tile = [&](Stage &g, uint32_t kk, uint32_t knext) {
+    auto tile = [&](Stage &g, uint32_t kk, uint32_t knext, uint32_t occ_next) {
         const uint32_t T = base + kk;
         const uint32_t bx = T % gx, t2 = T / gx, by = t2 % gy, plane = t2 / gy;
         const int kh0s = (int)(by * IW_TH) / 2, kw0s = (int)(bx * IW_TW) / 2;
@@ -1106,7 +1121,7 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
         // loads -- and looked at only at the end of the tile (raw: a subtraction here would wait for the answer)
         uint32_t drawn = 0;
         if (myctr && tid == 0) drawn = atomicAdd(myctr, 1u);
-        request(g, base + min(knext, cnt - 1u));  // unconditional (past the end: the last tile again, never used): a
+        request(g, base + min(knext, cnt - 1u), occ_next);  // unconditional (past the end: the last tile again, never used): a
         lds_barrier();                            // branch around loads makes every later wait a wait for all of them
         // ---- thread = (output column nn, half): as k_idwt_level ----
         const int m0 = (int)by * IW_TH, n0 = (int)bx * IW_TW, kh0 = m0 / 2;
@@ -1180,20 +1195,26 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     // a decoder instead of two and was slower there: 9.2-10.6 instead of 7.2 ms for level 1.)
     Stage g0;
     if (k >= cnt) return;
-    request(g0, base + k);
+    auto occupancy = [&](uint32_t kk) -> uint32_t {  // the L1Flags word of position kk of this XCD's range (clamped as the request is)
+        return FLAGS ? a.flags[base + min(kk, cnt - 1u)] : 1u;
+    };
+    request(g0, base + k, occupancy(k));
+    uint32_t occ_n = occupancy(kn);
     // The first tile stands outside the loop: inside it the wait for a tile's samples can then be "all but the stores
     // issued since" on every path into the loop head (with the first trip inside, nothing follows the samples' loads on
     // the path from above, and the compiler has to make it a wait for everything -- the stores of the tile before).
 #if IWP_PEEL
-    tile(g0, k, kn);
+    tile(g0, k, kn, occ_n);
     k = kn;
     kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;  // (s_next[0] is written again only behind the
                                                                          // next tile's first barrier)
+    occ_n = occupancy(kn);
 #endif
     while (k < cnt) {
-        tile(g0, k, kn);
+        tile(g0, k, kn, occ_n);
         k = kn;
         kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;
+        occ_n = occupancy(kn);
     }
 }
 
@@ -1403,7 +1424,9 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
             if (ctr) tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
         }
         if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
-        else hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
+        else if (a.flags && (uint64_t)a.enc_h * a.enc_w * 4u < (1ull << 31))
+            hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
+        else { a.flags = nullptr; hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess && ctr) {  // the launch did not happen: counters and book-keeping start over together
             (void)hipMemsetAsync(tc->dev, 0, 8 * 32 * sizeof(uint32_t), st);

@@ -240,7 +240,8 @@ def test_pyramid_codes_written_by_forward_level1(oracle, case):
     from spiht_amd import _lib
     from spiht_amd.batch import DeviceArray
     c, H, W, wavelet, mode, level = case
-    L, ctx, vp = _lib.lib(), _lib.default_context(), C.c_void_p
+    L, ctx, vp = _lib.lib(), _lib.Context(0), C.c_void_p
+    ctx.set_option("d1_emit", 1)  # (not the default: DESIGN.md 6)
     wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
     lv = -1 if level is None else level
     v = [C.c_int64() for _ in range(6)]
@@ -310,3 +311,79 @@ def test_maxabs_small_batch_after_large_batch(oracle):
             for b in range(B):
                 assert res[b].max_n == want[name][b][1], (name, b)
                 assert res[b].encoded_bytes == want[name][b][0], (name, b)
+
+
+# (c, H, W, wavelet, level, bits per pixel): halos of 0, 2, 4 and 8 band positions, odd band sizes, bands smaller than a tile
+L1F_CASES = [(3, 270, 480, "bior2.2", 5, 0.5), (1, 333, 517, "bior4.4", 4, 1.0), (2, 200, 264, "bior6.8", 3, 2.0),
+             (1, 129, 257, "haar", 2, 0.25), (3, 1080, 1920, "bior2.2", 7, 0.5), (1, 70, 90, "bior2.2", 1, 1.0)]
+
+
+@pytest.mark.parametrize("case", L1F_CASES)
+def test_level1_tile_occupancy_words(oracle, case):
+    """The list decoder leaves one word per (plane, tile) of the inverse transform's level 1 (common.h: L1Flags) and the
+    inverse level-1 kernels do not read the detail bands of a tile whose word is zero.  Checked here: (i) wherever a word
+    is zero, every detail-band cell the tile stages -- its own 12 x 64 band positions and the halo of F/2 - 1 behind them --
+    is zero in the decoded array; (ii) the picture is the same, bit for bit, with and without the words, and equals the
+    oracle's (waverec2 of the dense array); (iii) at the lower rates most words are zero (the point of it)."""
+    from spiht_amd import _lib
+    from spiht_amd.batch import BatchCodec, DeviceArray
+    from spiht_amd.spiht_wrapper import SpihtSettings
+    c, H, W, wavelet, level, bpp = case
+    F = {"haar": 2, "bior2.2": 6, "bior4.4": 10, "bior6.8": 18}[wavelet]
+    B = 2
+    L, ctx, vp = _lib.lib(), _lib.default_context(), C.c_void_p
+    s = SpihtSettings(wavelet=wavelet)
+    mb = int(H * W * bpp)
+    cd = BatchCodec(c, H, W, s, level, mb, ctx=ctx)
+    g = cd.geom
+    imgs = np.stack([synth_image(700 + b, c, H, W) for b in range(B)])
+    res = cd.encode(imgs)
+    stride = max(4, (max(len(r.encoded_bytes) for r in res) + 3) & ~3)
+    data = np.zeros((B, stride), np.uint8)
+    for b, r in enumerate(res):
+        data[b, :len(r.encoded_bytes)] = np.frombuffer(r.encoded_bytes, np.uint8)
+    d_data, d_nb, d_mn = DeviceArray(ctx, data.shape, np.uint8), DeviceArray(ctx, (B,), np.uint64), DeviceArray(ctx, (B,), np.uint8)
+    d_data.upload(data)
+    d_nb.upload(np.array([len(r.encoded_bytes) for r in res], np.uint64))
+    d_mn.upload(np.array([r.max_n for r in res], np.uint8))
+    n = c * g["enc_h"] * g["enc_w"]
+    d_rec = DeviceArray(ctx, (B, n), np.int32)
+    d_rec.zero()
+    nw = C.c_uint64()
+    _lib.check(L.spiht_l1_flags_words(c, H, W, cd.wid, cd._lv, C.byref(nw)))
+    assert (nw.value > 0) == (g["level"] >= 2)
+    d_fl = DeviceArray(ctx, (B, max(nw.value, 1)), np.uint32)
+    ctx.memset(d_fl.ptr, 0xEE, d_fl.nbytes)  # (the call zero-fills them itself)
+    _lib.check(L.spiht_decode_lists_flags_batch_i32(ctx.handle, vp(d_data.ptr), stride, vp(d_nb.ptr), vp(d_mn.ptr), B, c, H, W,
+                                                    cd.wid, cd._lv, vp(d_rec.ptr), vp(d_fl.ptr if nw.value else None)))
+    outs = []
+    for fl in (d_fl.ptr if nw.value else None, None):
+        d_img = DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64)
+        _lib.check(L.spiht_dequant_idwt_flags_batch_f64(ctx.handle, vp(d_rec.ptr), vp(fl), B, c, H, W, cd.wid, cd.mid, cd._lv,
+                                                        float(s.quantization_scale), None, vp(d_img.ptr)))
+        ctx.synchronize()
+        outs.append(d_img.download())
+        d_img.free()
+    assert np.array_equal(outs[0], outs[1])
+    rec = d_rec.download().reshape(B, c, g["enc_h"], g["enc_w"])
+    for b in range(B):
+        ref = oracle.decode_image(res[b].encoded_bytes, res[b].max_n, c, H, W, wavelet, level, float(s.quantization_scale), None)
+        assert np.array_equal(outs[0][b], ref)
+    if nw.value:
+        hs, ws = (H + F - 1) // 2, (W + F - 1) // 2          # level-1 band size
+        oh, ow = g["enc_h"] - hs, g["enc_w"] - ws              # its offsets in the packed array
+        gy, gx = (2 * hs - F + 2 + 23) // 24, (2 * ws - F + 2 + 127) // 128
+        assert nw.value == c * gy * gx
+        fl = d_fl.download().reshape(B, c, gy, gx)
+        assert set(np.unique(fl)) <= {0, 1}
+        bands = np.stack([rec[:, :, :hs, ow:ow + ws], rec[:, :, oh:oh + hs, :ws], rec[:, :, oh:oh + hs, ow:ow + ws]], axis=2) != 0
+        occ = bands.any(axis=2)  # [B, c, hs, ws]: some detail band holds a value at this band position
+        hf1 = F // 2 - 1
+        for ty in range(gy):
+            for tx in range(gx):
+                staged = occ[:, :, 12 * ty:12 * ty + 12 + hf1, 64 * tx:64 * tx + 64 + hf1].any(axis=(2, 3))
+                assert not (staged & (fl[:, :, ty, tx] == 0)).any(), (ty, tx)
+        if bpp <= 0.5:
+            assert fl.mean() < 0.5, float(fl.mean())
+    for a in (d_data, d_nb, d_mn, d_rec, d_fl):
+        a.free()
