@@ -34,7 +34,9 @@ enum {
 
 /* signal extension modes of the DWT (pywt names) */
 enum { SPIHT_MODE_REFLECT = 0, SPIHT_MODE_SYMMETRIC = 1, SPIHT_MODE_PERIODIC = 2, SPIHT_MODE_ZERO = 3,
-       SPIHT_MODE_CONSTANT = 4 };
+       SPIHT_MODE_CONSTANT = 4,
+       /* the modes whose extended samples are computed, not picked: a slower two-pass forward transform, float64 pixels */
+       SPIHT_MODE_SMOOTH = 5, SPIHT_MODE_ANTISYMMETRIC = 6, SPIHT_MODE_ANTIREFLECT = 7 };
 
 #define SPIHT_MAX_BITS_UNLIMITED 0xFFFFFFFFFFFFFFFFull
 
@@ -142,8 +144,12 @@ int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_
 
 /* Geometry of the packed coefficient array for an H x W image (wrapper:92-139, pywt.wavedecn_shapes).
  * level < 0 means "None" (pywt's maximum useful level).  Any out pointer may be NULL. */
-int spiht_wavelet_id(const char *name);           /* "bior2.2", "bior4.4", "bior6.8", "haar"/"db1"; <0 if unknown */
-int spiht_mode_id(const char *name);              /* "reflect", "symmetric", "periodic", "zero", "constant"; <0 if unknown */
+/* Every discrete wavelet of PyWavelets with at most 20 taps (the reference hands SpihtSettings.wavelet to pywt as it is,
+ * spiht_wrapper.py:163, :276): haar, db1-10, sym2-10, coif1-3, bior / rbio 1.1 ... 6.8 (csrc/wavelets.h, generated from
+ * PyWavelets by tools/gen_wavelets.py).  Ids are positions in that table: bior2.2 = 0, bior4.4 = 1, bior6.8 = 2, haar = 3. */
+int spiht_wavelet_id(const char *name);           /* < 0 if unknown (or longer than 20 taps) */
+int spiht_wavelet_taps(int wavelet);              /* filter length (pywt dec_len); < 0: no such id */
+int spiht_mode_id(const char *name);              /* the pywt names of the modes above; <0 if unknown ("periodization": not built) */
 int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h, int64_t *ll_w,
                    int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W);
 
@@ -242,7 +248,10 @@ int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, con
                                        const double *channel_mults, double *d_img_out);
 /* Switches of this library's own making; the results are the same bits whatever they are set to.  "d1_emit" (default 0):
  * level 1 of the forward transform writes significance-pyramid codes ahead of the pyramid pass; "l1_flags" (default 1):
- * the occupancy words above inside the image-level decode calls.  value 0 / 1. */
+ * the occupancy words above inside the image-level decode calls; "pads_persist" (default 0): the caller promises that a
+ * coefficient array this context's forward transform has filled is not written by anyone else before the same context
+ * fills it again with the same geometry -- the zero padding of coeffs_to_array is then written once per array instead
+ * of once per call (a caller that recycles its arrays, e.g. the pipelined schedule).  value 0 / 1. */
 int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
 
 /* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels

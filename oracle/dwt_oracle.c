@@ -36,47 +36,17 @@ typedef struct {
     double dec_lo[MAXF], dec_hi[MAXF], rec_lo[MAXF], rec_hi[MAXF];
 } wavelet_t;
 
-/* pywt.Wavelet(name).filter_bank, repr(float) (cross-checked by make_golden.py) */
+/* pywt.Wavelet(name).filter_bank, repr(float), of every discrete wavelet with at most 20 taps (generated
+ * from PyWavelets 1.1.1 by tools/gen_wavelets.py oracle; cross-checked against the library by tests/golden/make_golden.py) */
 static const wavelet_t WAVELETS[] = {
-    {"bior2.2", 6,
-     {0.0, -0.1767766952966369, 0.3535533905932738, 1.0606601717798212, 0.3535533905932738, -0.1767766952966369},
-     {0.0, 0.3535533905932738, -0.7071067811865476, 0.3535533905932738, 0.0, 0.0},
-     {0.0, 0.3535533905932738, 0.7071067811865476, 0.3535533905932738, 0.0, 0.0},
-     {0.0, 0.1767766952966369, 0.3535533905932738, -1.0606601717798212, 0.3535533905932738, 0.1767766952966369}},
-    {"bior4.4", 10,
-     {0.0, 0.03782845550726404, -0.023849465019556843, -0.11062440441843718, 0.37740285561283066,
-      0.8526986790088938, 0.37740285561283066, -0.11062440441843718, -0.023849465019556843, 0.03782845550726404},
-     {0.0, -0.06453888262869706, 0.04068941760916406, 0.41809227322161724, -0.7884856164055829,
-      0.41809227322161724, 0.04068941760916406, -0.06453888262869706, 0.0, 0.0},
-     {0.0, -0.06453888262869706, -0.04068941760916406, 0.41809227322161724, 0.7884856164055829,
-      0.41809227322161724, -0.04068941760916406, -0.06453888262869706, 0.0, 0.0},
-     {0.0, -0.03782845550726404, -0.023849465019556843, 0.11062440441843718, 0.37740285561283066,
-      -0.8526986790088938, 0.37740285561283066, 0.11062440441843718, -0.023849465019556843, -0.03782845550726404}},
-    {"bior6.8", 18,
-     {0.0, 0.0019088317364812906, -0.0019142861290887667, -0.016990639867602342, 0.01193456527972926,
-      0.04973290349094079, -0.07726317316720414, -0.09405920349573646, 0.4207962846098268, 0.8259229974584023,
-      0.4207962846098268, -0.09405920349573646, -0.07726317316720414, 0.04973290349094079, 0.01193456527972926,
-      -0.016990639867602342, -0.0019142861290887667, 0.0019088317364812906},
-     {0.0, 0.0, 0.0, 0.014426282505624435, -0.014467504896790148, -0.07872200106262882, 0.04036797903033992,
-      0.41784910915027457, -0.7589077294536541, 0.41784910915027457, 0.04036797903033992, -0.07872200106262882,
-      -0.014467504896790148, 0.014426282505624435, 0.0, 0.0, 0.0, 0.0},
-     {0.0, 0.0, 0.0, 0.014426282505624435, 0.014467504896790148, -0.07872200106262882, -0.04036797903033992,
-      0.41784910915027457, 0.7589077294536541, 0.41784910915027457, -0.04036797903033992, -0.07872200106262882,
-      0.014467504896790148, 0.014426282505624435, 0.0, 0.0, 0.0, 0.0},
-     {0.0, -0.0019088317364812906, -0.0019142861290887667, 0.016990639867602342, 0.01193456527972926,
-      -0.04973290349094079, -0.07726317316720414, 0.09405920349573646, 0.4207962846098268, -0.8259229974584023,
-      0.4207962846098268, 0.09405920349573646, -0.07726317316720414, -0.04973290349094079, 0.01193456527972926,
-      0.016990639867602342, -0.0019142861290887667, -0.0019088317364812906}},
-    {"haar", 2,
-     {0.7071067811865476, 0.7071067811865476},
-     {-0.7071067811865476, 0.7071067811865476},
-     {0.7071067811865476, 0.7071067811865476},
-     {0.7071067811865476, -0.7071067811865476}},
+#include "wavelets_table.h"
 };
 #define NWAVELETS ((int)(sizeof(WAVELETS) / sizeof(WAVELETS[0])))
 
 /* modes: 0 reflect, 1 symmetric, 2 periodic, 3 zero, 4 constant */
-enum { MODE_REFLECT = 0, MODE_SYMMETRIC = 1, MODE_PERIODIC = 2, MODE_ZERO = 3, MODE_CONSTANT = 4 };
+enum { MODE_REFLECT = 0, MODE_SYMMETRIC = 1, MODE_PERIODIC = 2, MODE_ZERO = 3, MODE_CONSTANT = 4,
+       /* ... and the extension modes of PyWavelets that are not index maps: the extended sample is computed */
+       MODE_SMOOTH = 5, MODE_ANTISYMMETRIC = 6, MODE_ANTIREFLECT = 7 };
 
 int orc_wavelet_id(const char *name) {
     for (int i = 0; i < NWAVELETS; i++)
@@ -152,6 +122,49 @@ static inline int64_t ext_index(int64_t i, int64_t N, int mode) {
     }
 }
 
+/* Sample i of the extended signal for the modes that compute it (pywt convolution.template.c, downsampling_convolution):
+ *   smooth         straight line through the two samples at the edge: x[0] + k (x[0] - x[1]) at distance k to the left,
+ *                  x[N-1] + k (x[N-1] - x[N-2]) to the right (N == 1: the edge value);
+ *   antisymmetric  the half-sample mirror image negated: blocks of N samples, every other one with the opposite sign
+ *                  (pywt subtracts the product: the same bits as adding the product with the negated sample);
+ *   antireflect    the whole-sample mirror image through the edge VALUE: le - (x[k] - x[0]) at distance k <= N-1 to the
+ *                  left with le = x[0]; the value reached at k = N-1 is the edge value of the next block, which runs
+ *                  back through the signal, le + (x[N-1-k] - x[N-1]); likewise to the right from re = x[N-1]. */
+static double ext_value(const double *x, int64_t N, int64_t sx, int64_t i, int mode) {
+    if (i >= 0 && i < N) return x[i * sx];
+    if (mode == MODE_SMOOTH) {
+        if (N < 2) return x[0];
+        if (i < 0) return x[0] + (double)(-i) * (x[0] - x[sx]);
+        return x[(N - 1) * sx] + (double)(i - N + 1) * (x[(N - 1) * sx] - x[(N - 2) * sx]);
+    }
+    if (mode == MODE_ANTISYMMETRIC) {
+        int64_t P = 2 * N, m = i % P;
+        if (m < 0) m += P;
+        int64_t b = (i - m) / N + (m >= N);   /* block number floor(i / N) */
+        const double v = x[(m < N ? m : P - 1 - m) * sx];
+        return (b & 1) ? -v : v;
+    }
+    /* antireflect */
+    if (N < 2) return x[0];
+    const int left = i < 0;
+    int64_t d = left ? -i : i - N + 1;
+    double e = left ? x[0] : x[(N - 1) * sx];
+    int fwd = 1;  /* the first block walks away from the edge it started at */
+    for (;;) {
+        const int64_t k = d <= N - 1 ? d : N - 1;
+        /* a block that starts at the left edge walks x[1], x[2], ...; one that starts at the right edge x[N-2], x[N-3], ... */
+        const int from_left = left ? fwd : !fwd;
+        const double t = from_left ? e - (x[k * sx] - x[0]) : e - (x[(N - 1 - k) * sx] - x[(N - 1) * sx]);
+        const double t2 = from_left ? e + (x[k * sx] - x[0]) : e + (x[(N - 1 - k) * sx] - x[(N - 1) * sx]);
+        /* first block of either side subtracts (mirror through the edge value); the block after it adds */
+        const double v = fwd ? t : t2;
+        if (d <= N - 1) return v;
+        e = v;
+        d -= N - 1;
+        fwd = !fwd;
+    }
+}
+
 /* 1-D analysis along a strided line.  Order of the additions as in pywt's downsampling_convolution
  * (convolution.template.c): taps in ascending order, except for the outputs that hang over the right end (2o+1 >= N)
  * of an input at least as long as the filter: there the taps that read the signal extension come first, nearest first
@@ -164,11 +177,17 @@ static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, c
     int64_t L = (N + F - 1) / 2;
     for (int64_t o = 0; o < L; o++) {
         double a = 0.0, d = 0.0;
-        int64_t i = 2 * o + 1, jb = (i >= N && N >= F && mode != MODE_CONSTANT) ? i - N : -1;
+        /* (smooth, like constant, adds its extension taps in ascending order) */
+        int64_t i = 2 * o + 1, jb = (i >= N && N >= F && mode != MODE_CONSTANT && mode != MODE_SMOOTH) ? i - N : -1;
         for (int s = 0; s < F; s++) {
             int j = s <= jb ? (int)(jb - s) : s;
-            int64_t idx = ext_index(i - j, N, mode);
-            double v = idx < 0 ? 0.0 : x[idx * sx];
+            double v;
+            if (mode >= MODE_SMOOTH) {
+                v = ext_value(x, N, sx, i - j, mode);
+            } else {
+                int64_t idx = ext_index(i - j, N, mode);
+                v = idx < 0 ? 0.0 : x[idx * sx];
+            }
             a += lo[j] * v;
             d += hi[j] * v;
         }

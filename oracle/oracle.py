@@ -21,11 +21,11 @@ _SO = os.path.join(_HERE, "liboracle.so")
 RULE_RUST = 0
 RULE_PY = 1
 
-MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4}
+MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4, "smooth": 5, "antisymmetric": 6, "antireflect": 7}
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c", "color_oracle.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("spiht_oracle.c", "dwt_oracle.c", "color_oracle.c", "wavelets_table.h")]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
         return _SO

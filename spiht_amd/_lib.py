@@ -48,7 +48,7 @@ SYMBOLS = [
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
-    "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
+    "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
 ]
 
 
@@ -106,6 +106,7 @@ def lib():
         L.spiht_decode_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i64, i64, vp]
         L.spiht_wavelet_id.argtypes = [C.c_char_p]
         L.spiht_mode_id.argtypes = [C.c_char_p]
+        L.spiht_wavelet_taps.argtypes = [i32]
         L.spiht_geometry.argtypes = [i64, i64, i32, i32, C.POINTER(i32)] + [C.POINTER(i64)] * 6
         L.spiht_encode_image_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, vp,
                                                    u64, vp, vp, vp]

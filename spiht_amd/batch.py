@@ -257,6 +257,9 @@ class OverlappedCodec:
         nw = C.c_uint64()
         _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec._lv, C.byref(nw)))
         self.flags = mk((B, nw.value), np.uint32) if nw.value and l1_flags else [None, None]
+        # the coefficient arrays are this object's own and only the forward transform writes them: their zero padding is
+        # written once per array, not once per step (beside a list decoder that launch of thin strips took 0.74 ms)
+        self.H.set_option("pads_persist", 1)
         for r in self.rec:  # zero once; from then on U keeps them zero
             self.H.memset(r.ptr, 0, r.nbytes)
         self.H.synchronize()
@@ -269,6 +272,24 @@ class OverlappedCodec:
 
     def contexts(self):
         return [self.H] + self.Ls
+
+    def close(self):
+        """give the arrays back (the promise about their padding ends with them)"""
+        if getattr(self, "coeffs", None):
+            try:
+                self.synchronize()
+            finally:
+                for d in self.coeffs + self.rec + self.dmsb + self.lmsb + self.maxabs + [f for f in self.flags if f] + \
+                        [a for a in self.approx if a]:
+                    d.free()  # (spiht_dev_free also drops what the context remembers about the array)
+                self.coeffs = None
+                self.H.set_option("pads_persist", 0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _idwt(self, s, d_img_out):
         cd = self.codec

@@ -33,6 +33,8 @@ int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nby
 int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
                         hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
+int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double *t_lo, double *t_hi, double *b_aa, double *b_ad, double *b_da,
+                               double *b_dd, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
                              double q, uint32_t *maxabs, hipStream_t st);
@@ -98,7 +100,11 @@ struct spiht_ctx {
     // spiht_ctx_set_option
     bool opt_d1_emit = false;   // level 1 of the forward transform writes pyramid codes ahead of the pyramid pass
     bool opt_l1_flags = true;   // the decoder flags the occupied level-1 tiles for the inverse transform
+    bool opt_pads_persist = false;  // coefficient arrays this context has filled keep their zero padding (see dwt_forward)
+    struct PadKey { const void *p; int planes; int64_t H, W; int F, L; };
+    std::vector<PadKey> pads_zeroed;  // arrays whose padding strips this context has zeroed (opt_pads_persist)
     DevBuf l1flags;             // L1Flags words of the fused decode path
+    DevBuf exttmp;              // intermediates of the two-pass forward level (extension modes that compute their samples)
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -114,10 +120,17 @@ struct spiht_ctx {
     uint64_t launches[ST_COUNT];
 };
 
+// memory at p goes back to the allocator: what is remembered about arrays there is void (option "pads_persist")
+static void forget_pads(spiht_ctx *ctx, const void *p) {
+    auto &v = ctx->pads_zeroed;
+    v.erase(std::remove_if(v.begin(), v.end(), [&](const spiht_ctx::PadKey &k) { return k.p == p; }), v.end());
+}
+
 static int ensure(spiht_ctx *ctx, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return SPIHT_OK;
     if (b.p) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        forget_pads(ctx, b.p);
         HIPCHK(hipFree(b.p));
         b.p = nullptr;
         b.cap = 0;
@@ -393,7 +406,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
+    DevBuf *bufs[] = {&ctx->exttmp, &ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
                       &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
@@ -978,10 +991,14 @@ extern "C" int spiht_wavelet_id(const char *name) {
     if (!strcmp(name, "db1")) return spiht_wavelet_id("haar");
     return -1;
 }
+// filter length of a wavelet of the table (pywt.Wavelet(name).dec_len); < 0: no such id
+extern "C" int spiht_wavelet_taps(int wavelet) {
+    return (wavelet >= 0 && wavelet < SPIHT_NWAVELETS) ? SPIHT_WAVELETS[wavelet].F : -1;
+}
 extern "C" int spiht_mode_id(const char *name) {
     if (!name) return -1;
-    static const char *names[] = {"reflect", "symmetric", "periodic", "zero", "constant"};
-    for (int i = 0; i < 5; i++)
+    static const char *names[] = {"reflect", "symmetric", "periodic", "zero", "constant", "smooth", "antisymmetric", "antireflect"};
+    for (int i = 0; i < 8; i++)
         if (!strcmp(names[i], name)) return i;
     return -1;
 }
@@ -1036,8 +1053,18 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         for (int l = 1; l <= ig.L; l++)
             if (ig.hs[l - 1] < wv.F || ig.ws[l - 1] < wv.F) return SPIHT_ERR_ARG;
     }
-    const bool color = ctx->color_on && c == 3;
+    bool color = ctx->color_on && c == 3;
     if (color && f32) return SPIHT_ERR_ARG;  // the colour model change is float64 (as colour-science's)
+    if (f32 && mode >= SPIHT_MODE_SMOOTH) return SPIHT_ERR_ARG;  // (single precision: the five index-map modes only)
+    if (color && mode >= SPIHT_MODE_SMOOTH && ig.L > 0) {
+        // the two-pass level has no colour form: the colour model change as a pass of its own in front of it
+        const size_t npix = (size_t)ig.hs[0] * ig.ws[0];
+        CHK(ensure(ctx, ctx->img, (size_t)planes * npix * 8));
+        LAUNCHCHK(spiht_launch_color3(d_img, (double *)ctx->img.p, planes / 3, npix, ctx->col_fwd.A, ctx->col_fwd.M, ctx->col_fwd.p,
+                                      ctx->stream));
+        d_img = (const double *)ctx->img.p;
+        color = false;
+    }
     if (ig.L == 0) {
         StageTimer t(ctx, ST_DWT_REST);
         if (color) {  // no transform level to carry the colour model change: a pass of its own
@@ -1049,11 +1076,26 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         LAUNCHCHK(spiht_launch_quant_plain(d_img, d_coeffs, plane_out, planes, c, d_mults, q, d_maxabs, ctx->stream));
         return SPIHT_OK;
     }
-    {
-        // zero padding cells of coeffs_to_array (thin strips; every other cell is written by a band)
+    // zero padding cells of coeffs_to_array (thin strips; every other cell is written by a band).  The transform writes
+    // band cells only, so an array it has filled once for this geometry still has its zeros the next time -- PROVIDED
+    // nobody else writes into it: a caller that owns its arrays says so (option "pads_persist": OverlappedCodec's
+    // double-buffered arrays; beside a list decoder this launch of thin strips took 0.74 instead of 0.12 ms per step).
+    bool pads_known = false;
+    const spiht_ctx::PadKey key = {d_coeffs, planes, ig.hs[0], ig.ws[0], wv.F, ig.L};
+    if (ctx->opt_pads_persist)
+        for (const auto &k : ctx->pads_zeroed)
+            pads_known = pads_known || (k.p == key.p && k.planes == key.planes && k.H == key.H && k.W == key.W && k.F == key.F && k.L == key.L);
+    if (!pads_known) {
         StageTimer t(ctx, ST_MEMSET);
         LAUNCHCHK(spiht_launch_zero_pads(ig.L, ig.hs, ig.ws, ig.offh, ig.offw, (int)ig.enc_h, (int)ig.enc_w, d_coeffs, planes,
                                          ctx->stream));
+        if (ctx->opt_pads_persist) {
+            // (an array seen with another geometry before has other strips: forget it)
+            auto &v = ctx->pads_zeroed;
+            v.erase(std::remove_if(v.begin(), v.end(), [&](const spiht_ctx::PadKey &k) { return k.p == key.p; }), v.end());
+            if (v.size() >= 8) v.erase(v.begin());
+            v.push_back(key);
+        }
     }
     if (ig.L >= 2) {
         CHK(ensure(ctx, ctx->a0, (size_t)planes * ig.hs[1] * ig.ws[1] * 8));
@@ -1086,7 +1128,27 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
             a.dmsb = d_dmsb;
             spiht_dwt_d1_cover(&a, cov);
         }
-        {
+        if (mode >= SPIHT_MODE_SMOOTH) {
+            // smooth / antisymmetric / antireflect: two plain passes through an intermediate (dwt.hip: k_dwt_axis_ext), a few
+            // planes at a time so that the intermediates stay under a gigabyte
+            StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
+            const size_t per_plane = ((size_t)2 * a.out_h * a.in_w + (size_t)4 * a.out_h * a.out_w) * 8;
+            int pc = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_plane);
+            pc = std::max(c, pc / c * c);  // whole images: the max|coefficient| word and the channel scale go by plane / c, plane % c
+            CHK(ensure(ctx, ctx->exttmp, per_plane * (size_t)std::min(pc, planes)));
+            for (int p0 = 0; p0 < planes; p0 += pc) {
+                const int np = std::min(pc, planes - p0);
+                DwtKArgs b = a;
+                b.in = a.in + (size_t)p0 * a.in_h * a.in_w;
+                if (b.ll_out) b.ll_out = a.ll_out + (size_t)p0 * a.out_h * a.out_w;
+                b.coeffs = a.coeffs + (size_t)p0 * a.enc_h * a.enc_w;
+                if (b.maxabs) b.maxabs = a.maxabs + p0 / c;
+                double *t_lo = (double *)ctx->exttmp.p, *t_hi = t_lo + (size_t)np * a.out_h * a.in_w;
+                double *b_aa = t_hi + (size_t)np * a.out_h * a.in_w, *b_ad = b_aa + (size_t)np * a.out_h * a.out_w;
+                double *b_da = b_ad + (size_t)np * a.out_h * a.out_w, *b_dd = b_da + (size_t)np * a.out_h * a.out_w;
+                LAUNCHCHK(spiht_launch_dwt_level_ext(&b, np, t_lo, t_hi, b_aa, b_ad, b_da, b_dd, ctx->stream));
+            }
+        } else {
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
             LAUNCHCHK(spiht_launch_dwt_level(&a, planes, ctx->stream));
         }
@@ -1172,7 +1234,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
 }
 
 static int check_img_args(int wavelet, int mode, int64_t B, int64_t c, int64_t H, int64_t W) {
-    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > 4) return SPIHT_ERR_ARG;
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > SPIHT_MODE_ANTIREFLECT) return SPIHT_ERR_ARG;
     if (B < 0 || c < 1 || H < 1 || W < 1) return SPIHT_ERR_ARG;
     if (H > (1 << 24) || W > (1 << 24)) return SPIHT_ERR_TOO_LARGE;
     return SPIHT_OK;
@@ -1690,6 +1752,7 @@ extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t va
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (!strcmp(name, "d1_emit")) ctx->opt_d1_emit = value != 0;
     else if (!strcmp(name, "l1_flags")) ctx->opt_l1_flags = value != 0;
+    else if (!strcmp(name, "pads_persist")) { ctx->opt_pads_persist = value != 0; ctx->pads_zeroed.clear(); }
     else return SPIHT_ERR_ARG;
     return SPIHT_OK;
 }
@@ -2038,6 +2101,10 @@ extern "C" int spiht_dev_free(spiht_ctx *ctx, void *d_ptr) {
     if (!ctx) return SPIHT_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    {
+        std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+        forget_pads(ctx, d_ptr);
+    }
     HIPCHK(hipFree(d_ptr));
     return SPIHT_OK;
 }

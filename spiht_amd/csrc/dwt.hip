@@ -23,6 +23,7 @@
 // HBM-bound: per level, 8 B per input sample + 8 B (LL) + 3*4 B (details) per output position.
 #include "common.h"
 #include <stdlib.h>
+#include <string.h>
 
 #ifndef DW_TH
 #define DW_TH 12      // output rows per tile.  Level 1 of 256 1080p images: 12 rows 3.8-3.95 ms, 16 rows 4.05-4.2, 14: 4.1,
@@ -813,6 +814,150 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
     }
 }
 
+// ---- forward level for the extension modes that COMPUTE the extended sample (smooth, antisymmetric, antireflect) ----------
+// PyWavelets' modes beyond the five index maps (the reference passes SpihtSettings.mode through, spiht_wrapper.py:163).
+// A sample outside the signal is a function of the samples at the edge, and along axis -1 pywt extends the INTERMEDIATE
+// (axis -2 already filtered) rows -- which is not the filtered extension of the pixels in the last bits -- so these modes
+// run as two plain passes, one thread per output, through a float64 intermediate in memory: correctness first, no tiling
+// (a path nobody's headline runs on; the tiled kernel above serves the index-map modes).  Summation order as pywt's
+// downsampling_convolution: taps ascending, except that on the right overhang of an input at least as long as the filter
+// the taps that read the extension come first, nearest first -- smooth, like constant, keeps ascending order there too.
+__device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, int i, int mode) {
+    if (i >= 0 && i < N) return x[(size_t)i * sx];
+    if (mode == 5) {  // smooth: the straight line through the two samples at the edge
+        if (N < 2) return x[0];
+        if (i < 0) return x[0] + (double)(-i) * (x[0] - x[sx]);
+        return x[(size_t)(N - 1) * sx] + (double)(i - N + 1) * (x[(size_t)(N - 1) * sx] - x[(size_t)(N - 2) * sx]);
+    }
+    if (mode == 6) {  // antisymmetric: half-sample mirror image, every other block of N samples negated
+        const int P = 2 * N;
+        int m = i % P;
+        if (m < 0) m += P;
+        const int blk = (i - m) / N + (m >= N ? 1 : 0);
+        const double v = x[(size_t)(m < N ? m : P - 1 - m) * sx];
+        return (blk & 1) ? -v : v;
+    }
+    // antireflect: whole-sample mirror image through the edge VALUE; the value a block ends on is the next block's edge
+    if (N < 2) return x[0];
+    const bool left = i < 0;
+    int d = left ? -i : i - N + 1;
+    double e = left ? x[0] : x[(size_t)(N - 1) * sx];
+    bool away = true;  // the first block walks away from the edge it started at and subtracts; the next one comes back and adds
+    for (;;) {
+        const int k = d <= N - 1 ? d : N - 1;
+        const bool from_left = left ? away : !away;
+        const double dlt = from_left ? x[(size_t)k * sx] - x[0] : x[(size_t)(N - 1 - k) * sx] - x[(size_t)(N - 1) * sx];
+        const double v = away ? e - dlt : e + dlt;
+        if (d <= N - 1) return v;
+        e = v;
+        d -= N - 1;
+        away = !away;
+    }
+}
+
+// one analysis pass along one axis: out position o of line `line` of plane `plane`.  n_lines lines of length N, element
+// stride sx, line stride sl; outputs: lo / hi [plane][L][n_lines] laid out with the same strides roles (so, sol)
+struct DwtAxisArgs {
+    int32_t F, mode, N, L, n_lines, planes;
+    size_t sx, sl, plane_in;     // input: element stride along the axis, stride between lines, plane stride
+    size_t so, sol, plane_out;   // output alike
+    const double *in;
+    double *lo, *hi;
+    double flo[SPIHT_MAX_TAPS], fhi[SPIHT_MAX_TAPS];
+};
+__global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_plane = (size_t)a.L * a.n_lines;
+    if (t >= per_plane * (size_t)a.planes) return;
+    const int plane = (int)(t / per_plane);
+    const size_t r = t - (size_t)plane * per_plane;
+    // consecutive threads along the contiguous direction of the output
+    int o, line;
+    if (a.so == 1) { line = (int)(r / a.L); o = (int)(r - (size_t)line * a.L); }
+    else { o = (int)(r / a.n_lines); line = (int)(r - (size_t)o * a.n_lines); }
+    const double *x = a.in + (size_t)plane * a.plane_in + (size_t)line * a.sl;
+    const int i = 2 * o + 1;
+    const int jb = (i >= a.N && a.N >= a.F && a.mode != 5) ? i - a.N : -1;
+    double sa = 0.0, sd = 0.0;
+    for (int s2 = 0; s2 < a.F; s2++) {
+        const int j = s2 <= jb ? jb - s2 : s2;
+        const double v = ext_value(x, a.N, a.sx, i - j, a.mode);
+        sa += a.flo[j] * v;
+        sd += a.fhi[j] * v;
+    }
+    const size_t oo = (size_t)plane * a.plane_out + (size_t)line * a.sol + (size_t)o * a.so;
+    a.lo[oo] = sa;
+    a.hi[oo] = sd;
+}
+// quantise + pack the four sub-bands of a level computed by the two passes: aa / ad from the low rows, da / dd from the high rows
+struct DwtPackArgs {
+    int32_t c, out_h, out_w, off_h, off_w, enc_h, enc_w, last, planes, pad;
+    const double *aa, *ad, *da, *dd;   // [planes, out_h, out_w]
+    double *ll_out;
+    int32_t *coeffs;
+    const double *mults;
+    uint32_t *maxabs;
+    double q;
+};
+__global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per = (size_t)a.out_h * a.out_w;
+    uint32_t amax = 0;
+    if (t < per * (size_t)a.planes) {
+        const int plane = (int)(t / per);
+        const size_t r = t - (size_t)plane * per;
+        const int oh = (int)(r / a.out_w), ow = (int)(r - (size_t)oh * a.out_w);
+        const bool has_m = a.mults != nullptr;
+        const double mk = has_m ? a.mults[plane % a.c] : 1.0;
+        int32_t *co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
+        const int32_t qad = quant(a.ad[t], mk, a.q, has_m), qda = quant(a.da[t], mk, a.q, has_m), qdd = quant(a.dd[t], mk, a.q, has_m);
+        if (a.last) {
+            const int32_t qaa = quant(a.aa[t], mk, a.q, has_m);
+            co[(size_t)oh * a.enc_w + ow] = qaa;
+            amax = iabs_u(qaa);
+        } else {
+            a.ll_out[t] = a.aa[t];
+        }
+        co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
+        co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
+        co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
+        amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
+        if (a.maxabs != nullptr && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+    }
+}
+// tmp: 6 arrays of planes*out_h*in_w (2) and planes*out_h*out_w (4) doubles, carved by the caller
+extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double *t_lo, double *t_hi, double *b_aa, double *b_ad,
+                                          double *b_da, double *b_dd, hipStream_t st) {
+    DwtAxisArgs x;
+    memset(&x, 0, sizeof(x));
+    x.F = a->F; x.mode = a->mode; x.planes = planes;
+    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; }
+    // axis -2: lines = columns
+    x.N = a->in_h; x.L = a->out_h; x.n_lines = a->in_w;
+    x.sx = (size_t)a->in_w; x.sl = 1; x.plane_in = (size_t)a->in_h * a->in_w;
+    x.so = (size_t)a->in_w; x.sol = 1; x.plane_out = (size_t)a->out_h * a->in_w;
+    x.in = a->in; x.lo = t_lo; x.hi = t_hi;
+    size_t n = (size_t)planes * x.L * x.n_lines;
+    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    // axis -1 on the low rows, then on the high rows: lines = rows
+    x.N = a->in_w; x.L = a->out_w; x.n_lines = a->out_h;
+    x.sx = 1; x.sl = (size_t)a->in_w; x.plane_in = (size_t)a->out_h * a->in_w;
+    x.so = 1; x.sol = (size_t)a->out_w; x.plane_out = (size_t)a->out_h * a->out_w;
+    n = (size_t)planes * x.L * x.n_lines;
+    x.in = t_lo; x.lo = b_aa; x.hi = b_ad;
+    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    x.in = t_hi; x.lo = b_da; x.hi = b_dd;
+    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    DwtPackArgs p;
+    memset(&p, 0, sizeof(p));
+    p.c = a->c; p.out_h = a->out_h; p.out_w = a->out_w; p.off_h = a->off_h; p.off_w = a->off_w; p.enc_h = a->enc_h; p.enc_w = a->enc_w;
+    p.last = a->last; p.planes = planes;
+    p.aa = b_aa; p.ad = b_ad; p.da = b_da; p.dd = b_dd;
+    p.ll_out = a->ll_out; p.coeffs = a->coeffs; p.mults = a->mults; p.maxabs = a->maxabs; p.q = a->q;
+    hipLaunchKernelGGL(k_dwt_pack_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
 // zero the padding cells of coeffs_to_array: per level the strip below 'ad' and the strip right of 'da'.
 // grid: (blocks, nrects, planes)
 struct PadRects {
@@ -1466,6 +1611,13 @@ extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t
     case 6: return launch_dwt_F<6, 0x3Eu, 0x0Eu>(*a, planes, st);          // bior2.2
     case 10: return launch_dwt_F<10, 0x3FEu, 0x0FEu>(*a, planes, st);      // bior4.4
     case 18: return launch_dwt_F<18, 0x3FFFEu, 0x3FF8u>(*a, planes, st);   // bior6.8
+    // every other even length up to SPIHT_MAX_TAPS (db / sym / coif / the other bior and rbio banks): all taps taken
+    case 4: return launch_dwt_F<4, 0xFu, 0xFu>(*a, planes, st);
+    case 8: return launch_dwt_F<8, 0xFFu, 0xFFu>(*a, planes, st);
+    case 12: return launch_dwt_F<12, 0xFFFu, 0xFFFu>(*a, planes, st);
+    case 14: return launch_dwt_F<14, 0x3FFFu, 0x3FFFu>(*a, planes, st);
+    case 16: return launch_dwt_F<16, 0xFFFFu, 0xFFFFu>(*a, planes, st);
+    case 20: return launch_dwt_F<20, 0xFFFFFu, 0xFFFFFu>(*a, planes, st);
     default: return -1;
     }
 }
@@ -1476,6 +1628,12 @@ extern "C" int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream
     case 6: return launch_idwt_F<6, 0x0Eu, 0x3Eu>(*a, planes, st, tc);          // bior2.2 rec_lo / rec_hi
     case 10: return launch_idwt_F<10, 0x0FEu, 0x3FEu>(*a, planes, st, tc);      // bior4.4
     case 18: return launch_idwt_F<18, 0x3FF8u, 0x3FFFEu>(*a, planes, st, tc);   // bior6.8
+    case 4: return launch_idwt_F<4, 0xFu, 0xFu>(*a, planes, st, tc);
+    case 8: return launch_idwt_F<8, 0xFFu, 0xFFu>(*a, planes, st, tc);
+    case 12: return launch_idwt_F<12, 0xFFFu, 0xFFFu>(*a, planes, st, tc);
+    case 14: return launch_idwt_F<14, 0x3FFFu, 0x3FFFu>(*a, planes, st, tc);
+    case 16: return launch_idwt_F<16, 0xFFFFu, 0xFFFFu>(*a, planes, st, tc);
+    case 20: return launch_idwt_F<20, 0xFFFFFu, 0xFFFFFu>(*a, planes, st, tc);
     default: return -1;
     }
 }

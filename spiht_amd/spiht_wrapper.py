@@ -66,11 +66,18 @@ def _wavelet_mode_ids(spiht_settings):
     L = _lib.lib()
     wid = L.spiht_wavelet_id(str(spiht_settings.wavelet).encode())
     if wid < 0:
-        raise ValueError("Unknown wavelet name '%s', supported: bior2.2, bior4.4, bior6.8, haar" % spiht_settings.wavelet)
+        # pywt.Wavelet(name) raises this ValueError for a name it does not know (spiht_wrapper.py:163 reaches it through
+        # wavedec2); the wavelets PyWavelets has with more than 20 taps (db11.., sym11.., coif4.., dmey) are refused too
+        raise ValueError("Unknown wavelet name '%s', check wavelist() for the list of available builtin wavelets "
+                         "(supported here: every discrete PyWavelets wavelet with at most 20 taps)." % spiht_settings.wavelet)
     mid = L.spiht_mode_id(str(spiht_settings.mode).encode())
     if mid < 0:
-        raise ValueError("Unknown mode name '%s', supported: reflect, symmetric, periodic, zero, constant"
-                         % spiht_settings.mode)
+        # pywt.Modes.from_object raises ValueError("Unknown mode name '...'.") (reached from spiht_wrapper.py:163)
+        if str(spiht_settings.mode) == "periodization":
+            raise ValueError("mode 'periodization' (PyWavelets' other length rule, ceil(n / 2) coefficients per level) is not "
+                             "supported; supported: reflect, symmetric, periodic, zero, constant, smooth, antisymmetric, "
+                             "antireflect")
+        raise ValueError("Unknown mode name '%s'." % spiht_settings.mode)
     return wid, mid
 
 
@@ -86,7 +93,10 @@ def _geometry(h, w, wid, level):
                 rec_h=v[4].value, rec_w=v[5].value)
 
 
-_FILTER_LEN = {"bior2.2": 6, "bior4.4": 10, "bior6.8": 18, "haar": 2, "db1": 2}
+def _filter_len(wavelet):
+    """pywt.Wavelet(name).dec_len, from the library's table"""
+    L = _lib.lib()
+    return L.spiht_wavelet_taps(L.spiht_wavelet_id(str(wavelet).encode()))
 
 
 def get_slices_and_h_w(h: int, w: int, spiht_settings: SpihtSettings, level: Optional[int]):
@@ -151,7 +161,7 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
     f32 = image.dtype in (np.float32, np.float16)
     img = np.ascontiguousarray(image, dtype=np.float32 if f32 else np.float64)
     if f32:
-        F = _FILTER_LEN[spiht_settings.wavelet]
+        F = _filter_len(spiht_settings.wavelet)
         hh, ww = h, w
         for _ in range(g["level"]):
             if hh < F or ww < F:
@@ -211,7 +221,7 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
 def _band_sizes(h, w, wavelet, levels):
     """band heights / widths per level, [0] = the image: len' = (len + F - 1) // 2 (pywt.dwt_coeff_len, every mode but
     periodization)"""
-    F = _FILTER_LEN[wavelet]
+    F = _filter_len(wavelet)
     hs, ws = [int(h)], [int(w)]
     for _ in range(levels):
         hs.append((hs[-1] + F - 1) // 2)

@@ -13,6 +13,10 @@ seeded inputs and stores inputs + outputs as .npz fixtures next to this file.
                                                (int32 rec array -> pixels), geometry, filter banks
                                                -> wrapper_pywt.npz
 
+  part "wavelets" / "modes" (python3.9, PyWavelets 1.1.1; PyWavelets alone, the reference is not imported)
+                                               every wavelet with at most 20 taps / the extension modes that are not index
+                                               maps and periodization -> wavelets_pywt.npz, modes_pywt.npz
+
   part "blocky"  (python3.9, PyWavelets 1.1.1)  float64 coefficient arrays of piecewise-constant images, bit for bit
                                                -> blocky_pywt.npz (pins the summation order at the right / bottom edge)
 
@@ -317,6 +321,82 @@ def part_blocky():
     print("wrote blocky_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
 
 
+def _transform_cases(out, cases, pywt):
+    """what the reference's wrapper does with SpihtSettings.wavelet / .mode around its coder (spiht_wrapper.py:163-172:
+    wavedec2 -> coeffs_to_array -> * q -> int32; :259-276: / q -> array_to_coeffs -> waverec2), with PyWavelets alone:
+    the float64 packed array (every bit), the int32 array, and the picture waverec2 gives back from a thinned-out copy of it"""
+    rng = np.random.default_rng(5)
+    for i, (seed, c, H, W, wv, lv, q, mode, blocky) in enumerate(cases):
+        img = blocky_image(seed, c, H, W) if blocky else synth_image(seed, c, H, W)
+        co = pywt.wavedec2(img, wavelet=wv, level=lv, mode=mode)
+        arr, slices = pywt.coeffs_to_array(co, axes=(-2, -1))
+        assert arr.dtype == np.float64
+        qa = np.ascontiguousarray((arr * q).astype(np.int32))
+        rec = (qa - (qa % 4) * (rng.random(qa.shape) < 0.5)).astype(np.int32)
+        back = pywt.waverec2(pywt.array_to_coeffs(rec / q, slices, output_format="wavedec2"), mode=mode, wavelet=wv)
+        p = "c%d_" % i
+        out[p + "meta"] = np.array([seed, c, H, W, lv, int(blocky)])
+        out[p + "wavelet"] = np.array(wv)
+        out[p + "mode"] = np.array(mode)
+        out[p + "q"] = np.array(q)
+        out[p + "arr"] = arr
+        out[p + "quant"] = qa
+        out[p + "rec"] = rec
+        out[p + "rec_img"] = back
+    out["ncases"] = np.array(len(cases))
+
+
+def part_wavelets():
+    """every discrete wavelet of PyWavelets with at most 20 taps (the reference hands SpihtSettings.wavelet straight to
+    pywt: spiht_wrapper.py:163, :276), small odd-sized pictures, two or three levels, the five index-mapping extension
+    modes in turn -> wavelets_pywt.npz"""
+    import pywt
+    names = [n for n in pywt.wavelist(kind="discrete") if pywt.Wavelet(n).dec_len <= 20]
+    modes = ["reflect", "symmetric", "periodic", "zero", "constant"]
+    rng = np.random.default_rng(123)
+    cases = []
+    for i, n in enumerate(names):
+        F = pywt.Wavelet(n).dec_len
+        H, W = int(rng.integers(2 * F + 3, 2 * F + 40)), int(rng.integers(2 * F + 3, 2 * F + 40))
+        lv = 1 + i % 3
+        while lv > 1 and min(H, W) < F * 2 ** (lv - 1):  # every level's input at least as long as the filter
+            lv -= 1
+        cases.append((400 + i, 1 + i % 2, H, W, n, lv, [50.0, 255.0, 10.0][i % 3], modes[i % len(modes)], i % 2 == 1))
+    out = {"pywt_version": np.array(pywt.__version__), "names": np.array(names),
+           "dec_len": np.array([pywt.Wavelet(n).dec_len for n in names])}
+    for n in names:
+        out["fb_" + n] = np.array(pywt.Wavelet(n).filter_bank, dtype=np.float64)
+    _transform_cases(out, cases, pywt)
+    np.savez_compressed(os.path.join(HERE, "wavelets_pywt.npz"), **out)
+    print("wrote wavelets_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
+
+
+def part_modes():
+    """the four extension modes of PyWavelets that are not index maps -- smooth, antisymmetric, antireflect -- and
+    periodization (another length rule: ceil(N / 2) per level), over several filter lengths, odd and even sizes, inputs
+    longer and (for the first three) shorter than the filter -> modes_pywt.npz"""
+    import pywt
+    rng = np.random.default_rng(321)
+    cases = []
+    wvs = ["bior2.2", "haar", "bior4.4", "db2", "sym4", "bior6.8", "coif1", "db7"]
+    k = 0
+    for mode in ["smooth", "antisymmetric", "antireflect", "periodization"]:
+        for j in range(10):
+            wv = wvs[(j + k) % len(wvs)]
+            F = pywt.Wavelet(wv).dec_len
+            H, W = int(rng.integers(F + 1, 4 * F + 30)), int(rng.integers(F + 1, 4 * F + 30))
+            lv = 1 + j % 3
+            if j < 8:
+                while lv > 1 and min(H, W) < F * 2 ** (lv - 1):
+                    lv -= 1
+            cases.append((600 + k, 1 + j % 2, H, W, wv, lv, [50.0, 255.0, 10.0][j % 3], mode, j % 2 == 0))
+            k += 1
+    out = {"pywt_version": np.array(pywt.__version__)}
+    _transform_cases(out, cases, pywt)
+    np.savez_compressed(os.path.join(HERE, "modes_pywt.npz"), **out)
+    print("wrote modes_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
+
+
 if __name__ == "__main__":
     {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32,
-     "blocky": part_blocky}[sys.argv[1]]()
+     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes}[sys.argv[1]]()

@@ -387,3 +387,77 @@ def test_level1_tile_occupancy_words(oracle, case):
             assert fl.mean() < 0.5, float(fl.mean())
     for a in (d_data, d_nb, d_mn, d_rec, d_fl):
         a.free()
+
+
+def test_every_wavelet_up_to_20_taps(oracle):
+    """SpihtSettings.wavelet goes to PyWavelets as it is in the reference (spiht_wrapper.py:163, :276): each of the 53
+    discrete wavelets with at most 20 taps on the GPU against PyWavelets 1.1.1 (tests/golden/wavelets_pywt.npz) -- the
+    int32 array handed to the coder, and the picture back from a thinned-out copy of it, bit for bit -- and against the
+    oracle on a multi-tile picture per filter length."""
+    from test_oracle import transform_cases
+    seen = {}
+    for cs in transform_cases("wavelets_pywt.npz"):
+        got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        bad = np.argwhere(got != cs["quant"])
+        assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, len(bad), bad[:4])
+        back = _gpu_idwt(cs["rec"][None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        assert back.shape == cs["rec_img"].shape and np.array_equal(back, cs["rec_img"]), (cs["wavelet"], cs["level"])
+        seen.setdefault(len(oracle.wavelet_filters(cs["wavelet"])[0]), cs["wavelet"])
+    assert len(seen) == 10  # filter lengths 2, 4, ..., 20
+    # larger than a tile in both directions, several levels, a batch: one wavelet per filter length
+    for F, wv in sorted(seen.items()):
+        imgs = np.stack([synth_image(70 + b, 2, 150, 301) for b in range(2)])
+        got = _gpu_dwt(imgs, wv, "reflect", 3, 50.0, [1.0, 0.5])
+        back = _gpu_idwt(got, 150, 301, wv, "reflect", 3, 50.0, [1.0, 0.5])
+        for b in range(2):
+            arr, _ = oracle.wavedec2_array(imgs[b], wv, "reflect", 3)
+            assert np.array_equal(got[b], oracle.quantize(arr, 50.0, [1.0, 0.5])), (wv, F)
+            ref = oracle.waverec2_array(oracle.dequantize(got[b], 50.0, [1.0, 0.5]), 150, 301, wv, 3)
+            assert np.array_equal(back[b], ref), (wv, F)
+    import spiht_amd
+    with pytest.raises(ValueError):
+        spiht_amd.encode_image(np.zeros((1, 64, 64)), spiht_amd.SpihtSettings(wavelet="db11"))   # 22 taps: refused
+    with pytest.raises(ValueError):
+        spiht_amd.encode_image(np.zeros((1, 64, 64)), spiht_amd.SpihtSettings(wavelet="nonsense"))
+
+
+def test_computed_extension_modes(oracle):
+    """smooth / antisymmetric / antireflect (the reference passes SpihtSettings.mode to PyWavelets as it is): the two-pass
+    forward level (dwt.hip: k_dwt_axis_ext) against PyWavelets 1.1.1 (tests/golden/modes_pywt.npz) and, on a batch of
+    pictures larger than a tile with channel scales and a colour model, against the oracle; the coder behind it included."""
+    import spiht_amd
+    from test_oracle import transform_cases
+    n = 0
+    for cs in transform_cases("modes_pywt.npz"):
+        if cs["mode"] == "periodization":
+            with pytest.raises(ValueError):
+                spiht_amd.encode_image(cs["img"], spiht_amd.SpihtSettings(wavelet=cs["wavelet"], mode=cs["mode"]), cs["level"])
+            continue
+        got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        bad = np.argwhere(got != cs["quant"])
+        assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, len(bad), bad[:4])
+        back = _gpu_idwt(cs["rec"][None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        assert np.array_equal(back, cs["rec_img"])
+        n += 1
+    assert n == 30
+    for mode in ("smooth", "antisymmetric", "antireflect"):
+        imgs = np.stack([synth_image(90 + b, 3, 131, 203) for b in range(3)])
+        got = _gpu_dwt(imgs, "bior4.4", mode, 3, 50.0, [1.0, 0.5, 2.0])
+        for b in range(3):
+            arr, _ = oracle.wavedec2_array(imgs[b], "bior4.4", mode, 3)
+            assert np.array_equal(got[b], oracle.quantize(arr, 50.0, [1.0, 0.5, 2.0])), mode
+        s = spiht_amd.SpihtSettings(mode=mode)
+        enc = spiht_amd.encode_image(imgs[0], s, 3, 20000)
+        ref_bytes, ref_n, _ = oracle.encode_image(imgs[0], "bior2.2", mode, 3, 50.0, None, 20000)
+        assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n, mode
+        dec = spiht_amd.decode_image(enc, s)
+        assert np.array_equal(dec, oracle.decode_image(ref_bytes, ref_n, 3, 131, 203, "bior2.2", 3, 50.0, None))
+        # with a colour model: the change runs as a pass of its own in front of the two-pass level
+        sc = spiht_amd.SpihtSettings(mode=mode, quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
+        e2 = spiht_amd.encode_image(imgs[1], sc, 3, 20000)
+        d2 = spiht_amd.decode_image(e2, sc)
+        assert np.abs(d2[:, :131, :203] - imgs[1]).mean() < 0.1
+    with pytest.raises(ValueError):
+        spiht_amd.encode_image(imgs[0], spiht_amd.SpihtSettings(mode="nonsense"), 2)
+    with pytest.raises(ValueError):  # single precision: the index-map modes only
+        spiht_amd.encode_image(imgs[0].astype(np.float32), spiht_amd.SpihtSettings(mode="smooth"), 2)
