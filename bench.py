@@ -148,7 +148,8 @@ def main():
                          "on; float32 runs the single-precision forward transform PyWavelets would run on such pixels (half the "
                          "DWT read traffic); the decode side is float64 either way, as in the reference")
     ap.add_argument("--pipeline", type=int, default=1,
-                    help="1 (default): steps are software-pipelined -- the HBM-bound halves (DWT + pyramid of step i+1, "
+                    help="1 (default) / 2: steps are software-pipelined, queued by the library's own spiht_pipeline_submit (1) or from "
+                         "Python by OverlappedCodec (2; also taken when --pair / --decoder-waves / --l1-flags ask for a variant) -- the HBM-bound halves (DWT + pyramid of step i+1, "
                          "inverse DWT of step i-1) run on one context while step i is list-coded on another "
                          "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  "
                          "0: every step runs its stages back to back on one stream, each kernel with the whole GPU")
@@ -174,6 +175,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SPIHT_BENCH_DEVICE"):  # rehearsal of N ranks on a box with fewer GPUs: every rank on this device
+        local_rank = int(os.environ["SPIHT_BENCH_DEVICE"])
     # under a launcher (RANK set) the distributed path is taken even with one rank, so it can be rehearsed on one GPU
     use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("SPIHT_BENCH_FORCE_DIST", "1") == "1")
 
@@ -276,8 +279,16 @@ def main():
         codecs[k].nbits_to_nbytes(sn + a * 8, b - a, d_nbytes.ptr + a * 8)
         codecs[k].decode_device(so + a * slot, d_nbytes.ptr + a * 8, sm + a, b - a, d_rec_img.ptr + a * rec_b)
 
-    pipe = None
-    if args.pipeline and K == 1 and pix == np.float64:
+    pipe = cpipe = None
+    if args.pipeline == 1 and K == 1 and pix == np.float64 and args.pair == "inverse" and args.decoder_waves == 8 and args.l1_flags:
+        # the same schedule queued by the library itself (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): what a
+        # caller in any host language gets; three contexts of its own
+        from spiht_amd.batch import Pipeline
+        cpipe = Pipeline(codec, B)
+        pctx = cpipe.contexts()
+        pctx[0].set_option("d1_emit", args.d1_emit)
+        ctxs.extend(pctx[1:])   # (its H context is `ctx`)
+    elif args.pipeline and K == 1 and pix == np.float64:
         # The HBM-bound halves (DWT+pyramid of step i+1, inverse DWT of step i-1) run on context H while context L
         # list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).  The
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
@@ -286,6 +297,10 @@ def main():
         ctxs.extend(pipe.Ls)
 
     def step():
+        if cpipe is not None:
+            cpipe.submit(d_img.ptr, out_ptr, nbits_ptr, maxn_ptr, d_rec_img.ptr, comm=comm,
+                         gathered=(g_out.ptr, g_nbits.ptr, g_maxn.ptr) if comm is not None else None, rank=rank)
+            return
         if pipe is not None:
             pipe.submit(d_img.ptr, out_ptr, nbits_ptr, maxn_ptr, d_nbytes.ptr, d_rec_img.ptr,
                         between=gather if comm is not None else None, dec_src=(dec_out, dec_nbits, dec_maxn))
@@ -303,6 +318,8 @@ def main():
             dec_chunk(k)
 
     def sync_all():
+        if cpipe is not None:
+            cpipe.flush()
         if pipe is not None:
             pipe.flush()  # the inverse transform of the last step (inside the timed region)
         for cx in ctxs:
@@ -435,7 +452,7 @@ def main():
         # the same kernels with the GPU to themselves (one serial round trip of the batch after the timed region): in
         # the pipelined schedule the numbers above are those of kernels that share the GPU with the list coder
         alone = None
-        if pipe is not None:
+        if pipe is not None or cpipe is not None:
             own = (out_ptr, nbits_ptr, maxn_ptr)
             enc_chunk(0)
             dec_chunk(0, own)
@@ -488,9 +505,28 @@ def main():
                     if other.get(key) is not None:
                         other[key]["traffic_bytes_per_image"] = round(ot[src]["hbm_bytes_per_image"])
                         other[key]["algorithmic_bytes_per_image"] = ot[src]["algorithmic_bytes_per_image"]
-                        other[key]["traffic_source"] = "profiles/hbm_traffic_other.json (committed PMC measurement, separate run)"
+                        other[key]["traffic_source"] = "profiles/hbm_traffic_other.json (committed PMC measurement, separate run, " \
+                                                       "%s images per launch)" % ot.get("images_per_launch", "?")
+                occ = ot.get("idwt_level1_with_occupancy_words", {}).get("%g bpp" % BPP)
+                if occ and other.get("idwt_level1") is not None and args.l1_flags:
+                    # what this run's inverse level 1 moves: the decoder's occupancy words are on, empty tiles' detail bands unread
+                    other["idwt_level1"]["with_occupancy_words"] = {k2: (round(v2) if k2.endswith("per_image") else v2)
+                                                                    for k2, v2 in occ.items()}
             except Exception:
                 pass
+        # every HBM pass of a step counted once: the transform levels in both directions + the pyramid
+        hh, ww, step_bytes = [H], [W], 0
+        for _l in range(g["level"]):
+            hh.append((hh[-1] + 6 - 1) // 2)
+            ww.append((ww[-1] + 6 - 1) // 2)
+        for _l in range(1, g["level"] + 1):
+            ll_b = 4 if _l == g["level"] else 8  # the coarsest approximation lives in the int32 array
+            step_bytes += 2 * C_IMG * (hh[_l - 1] * ww[_l - 1] * 8 + hh[_l] * ww[_l] * (ll_b + 12))
+        step_bytes = B * (step_bytes + 4 * n_coef + n_par + n_par // 4)
+        whole = {"algorithmic_bytes_per_step": step_bytes, "achieved_GBps": round(step_bytes / (dt / args.steps) / 1e9, 1),
+                 "frac": round(step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                 "what": "every HBM pass of the step once (7 forward + 7 inverse levels, pyramid) / ms_per_step; the list coder's own "
+                         "traffic (a few MB per image) not counted"}
         result = {
             "metric": "Mpixels/sec encode+decode at fixed bpp; bitstream-exact vs Rust ref",
             "value": round(mpix, 2),
@@ -508,22 +544,27 @@ def main():
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
                        "images_per_gpu": B, "distinct_images_per_gpu": nd, "seeds": "1000 + global image index",
                        "streams": K, "images_per_launch": per_launch,
-                       "decoder_waves": args.decoder_waves if pipe is not None else 12,
+                       "decoder_waves": args.decoder_waves if (pipe is not None or cpipe is not None) else 12, "l1_flags": bool(args.l1_flags),
+                       "d1_emit": bool(args.d1_emit),
                        "schedule": ("steps software-pipelined: HBM-bound passes of steps i+1 / i-1 on one stream while step i is "
-                                    "list-coded on another" if pipe is not None else "stages back to back"),
+                                    "list-coded on another" + (", queued by the library (spiht_pipeline_submit)" if cpipe is not None
+                                                               else ", queued from Python (OverlappedCodec)")
+                                    if (pipe is not None or cpipe is not None) else "stages back to back"),
                        "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]],
-                       "gather": (dict(comm.info(), where="spiht_gather_streams (ncclAllGather on the list-coding stream); "
-                                                        "every rank decodes its rows of the gathered buffer")
+                       "gather": (dict(comm.info(), library=_lib.lib().spiht_rccl_library().decode(),
+                                       where="spiht_gather_streams (ncclAllGather on the list-coding stream); "
+                                             "every rank decodes its rows of the gathered buffer")
                                   if comm is not None else
-                                  ({"failed": comm_error, "note": "RCCL did not come up: every rank coded and decoded its own "
+                                  ({"failed": comm_error, "library": _lib.lib().spiht_rccl_library().decode(),
+                                    "note": "RCCL did not come up: every rank coded and decoded its own "
                                     "shard, no stream gather took place"} if comm_error else None))},
             "roofline": {"bound": "hbm", "kernel": ("k_dwt_level<6>" if pix == np.float64 else "k_dwt_level_f32<6>") +
                          " (forward DWT level 1, fused quantise)",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": dwt_bytes, "avg_launch_ms": round(avg_ms, 4),
-                         "kernel_alone": alone},
+                         "kernel_alone": alone, "whole_step": whole},
             "stages_ms_per_step_summed_over_streams": {k: round(v[0] / args.steps, 3) for k, v in stages.items() if v[1]},
             "roofline_other_hbm_passes": other,
             "single_image_latency": single,

@@ -184,7 +184,8 @@ int spiht_dequant_idwt_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, int64_t B
  * float32 (and float16) pixels in float32 and the reference wrapper quantises the float32 array in float32
  * (`pywt.wavedec2` dtype rule, spiht_wrapper.py:163-172) -- so a float32 image does not give the stream its float64
  * copy gives; these reproduce the float32 result, including pywt's order of additions at the right / bottom edge.
- * SPIHT_ERR_ARG when a level's input is shorter than the filter (level above pywt's dwt_max_level) or level == 0.
+ * (Levels above pywt's dwt_max_level -- inputs shorter than the filter -- are coded as PyWavelets codes them, in either
+ * precision: it only warns, spiht_wrapper.py:163.)  SPIHT_ERR_ARG for level == 0.
  * The decode side is float64 in the reference whatever the pixels were. */
 int spiht_dwt_quant_batch_f32(spiht_ctx *ctx, const float *d_img, int64_t B, int64_t c, int64_t H, int64_t W,
                               int wavelet, int mode, int level, double q_scale, const double *channel_mults,
@@ -356,10 +357,50 @@ int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *comm, const uint8_t *d_slot
 /* The RCCL shared library this process uses: the soname that was loaded, or every candidate tried with the loader's
  * reason when none could be ("" before the first spiht_comm_* call).  For the job's log line. */
 const char *spiht_rccl_library(void);
+/* spiht_pipeline_submit with the gather of a multi-GPU job in it (see the pipeline section below) */
+typedef struct spiht_pipeline spiht_pipeline;
+int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits, uint8_t *d_max_n,
+                                 double *d_img_out, spiht_comm *comm, uint8_t *d_all_slots, uint64_t *d_all_nbits,
+                                 uint8_t *d_all_max_n, int rank);
 /* Host-side job control over the same communicator (both block): every rank has arrived and its context's queue is
  * empty; *value becomes the maximum over ranks. */
 int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *comm);
 int spiht_comm_allreduce_max_f64(spiht_ctx *ctx, spiht_comm *comm, double *value);
+
+/* ---------------------------------------------------------------------------------------
+ * The pipelined round trip (csrc/pipeline.cpp): B images per step, pixels -> streams -> pixels, consecutive steps
+ * software-pipelined over three contexts the pipeline owns -- the HBM-bound passes of steps i+1 / i-1 on one, the list
+ * coder of step i on another -- ordered with events; no call blocks the host except _synchronize.  This is the schedule
+ * the throughput metric is measured on (bench.py); it replaces a caller's loop over the reference's one-image calls
+ * (spiht_wrapper.py:142-216).  All image / stream pointers are DEVICE pointers as in the batched calls above and must stay
+ * valid until the step that uses them has completed (d_out / d_nbits / d_max_n may be the same for every step: a step's
+ * decoder has read them before the next step's encoder writes them).
+ *   create        geometry and settings as spiht_encode_image_batch_f64; max_bits 0 = unlimited
+ *   info          stream slot size in bytes (spiht_encode_bound) and the decoded picture size
+ *   set_color3    colour model of the coded picture (spiht_ctx_set_color3) for every step
+ *   submit        queue one step; the decoded pictures of step i are complete after submit of step i+1 has been followed
+ *                 by _synchronize -- or after _flush + waiting
+ *   submit_gather the same in a multi-GPU job: the streams are all-gathered (spiht_gather_streams) between encoder and
+ *                 decoder on the list-coding stream, and the decoder reads rows [rank*B, (rank+1)*B) of the gathered buffers
+ *   flush         queue the inverse transform of the last submitted step
+ *   synchronize   flush, then wait for everything; returns the first latched device error
+ *   contexts      the three contexts (stage timing: spiht_ctx_set_timing / _get_timing) */
+typedef struct spiht_pipeline spiht_pipeline;
+int spiht_pipeline_create(int device, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level,
+                          double q_scale, const double *channel_mults, uint64_t max_bits, spiht_pipeline **out);
+/* ... the HBM-bound passes on the caller's context h_ctx (on `device`; not destroyed with the pipeline): a process has few
+ * hardware queues for its HIP streams, a caller that holds a context already should not add a fourth stream */
+int spiht_pipeline_create_on(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode,
+                             int level, double q_scale, const double *channel_mults, uint64_t max_bits, spiht_pipeline **out);
+void spiht_pipeline_destroy(spiht_pipeline *p);
+int spiht_pipeline_info(spiht_pipeline *p, uint64_t *slot_stride, int64_t *rec_H, int64_t *rec_W);
+int spiht_pipeline_set_color3(spiht_pipeline *p, const double *A_f, const double *M_f, double p_f, const double *A_i,
+                              const double *M_i, double p_i);
+int spiht_pipeline_submit(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits, uint8_t *d_max_n,
+                          double *d_img_out);
+int spiht_pipeline_flush(spiht_pipeline *p);
+int spiht_pipeline_synchronize(spiht_pipeline *p);
+int spiht_pipeline_contexts(spiht_pipeline *p, spiht_ctx **h, spiht_ctx **l0, spiht_ctx **l1);
 
 /* Thin device-memory helpers so a host language without a HIP binding can drive the batched API. */
 int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr);

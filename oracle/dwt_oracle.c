@@ -166,19 +166,19 @@ static double ext_value(const double *x, int64_t N, int64_t sx, int64_t i, int m
 }
 
 /* 1-D analysis along a strided line.  Order of the additions as in pywt's downsampling_convolution
- * (convolution.template.c): taps in ascending order, except for the outputs that hang over the right end (2o+1 >= N)
- * of an input at least as long as the filter: there the taps that read the signal extension come first, nearest first
- * (filter index 2o+1-N down to 0), then the others ascending.  (Constant-edge mode adds the replicated-edge taps in
- * ascending order too; inputs shorter than the filter go through another loop of pywt's, restated here as plain
- * ascending order.)  The truncating quantiser sees the difference on piecewise-constant 8-bit pictures:
- * tests/golden/blocky_pywt.npz holds pywt's arrays bit for bit. */
+ * (convolution.template.c): taps in ascending order, except for the outputs that hang over the right end of the input
+ * (2o+1 >= N): there the taps that read the signal extension come first, nearest first (filter index 2o+1-N down to 0),
+ * then the others ascending -- through the signal and, when the input is shorter than the filter, on into the left-hand
+ * extension (tests/golden/short_pywt.npz).  Constant-edge and smooth add their extension taps in ascending order too.
+ * The truncating quantiser sees the difference on piecewise-constant 8-bit pictures: tests/golden/blocky_pywt.npz holds
+ * pywt's arrays bit for bit. */
 static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, const double *hi, int F,
                      int mode, double *ca, double *cd, int64_t so) {
     int64_t L = (N + F - 1) / 2;
     for (int64_t o = 0; o < L; o++) {
         double a = 0.0, d = 0.0;
         /* (smooth, like constant, adds its extension taps in ascending order) */
-        int64_t i = 2 * o + 1, jb = (i >= N && N >= F && mode != MODE_CONSTANT && mode != MODE_SMOOTH) ? i - N : -1;
+        int64_t i = 2 * o + 1, jb = (i >= N && mode != MODE_CONSTANT && mode != MODE_SMOOTH) ? i - N : -1;
         for (int s = 0; s < F; s++) {
             int j = s <= jb ? (int)(jb - s) : s;
             double v;
@@ -394,16 +394,14 @@ static void dwt_line_f(const float *x, int64_t N, int64_t sx, const float *lo, c
     }
 }
 
-/* float32 wavedec2 + coeffs_to_array; arr [c,enc_h,enc_w] float, zero padded.  Returns -3 when a level's input is
- * shorter than the filter (pywt then runs a different loop whose order is not restated here). */
+/* float32 wavedec2 + coeffs_to_array; arr [c,enc_h,enc_w] float, zero padded. */
 int orc_wavedec2_array_f32(const float *img, int64_t c, int64_t H, int64_t W, int wid, int mode, int level, float *arr) {
     if (wid < 0 || wid >= NWAVELETS) return -1;
     const wavelet_t *wv = &WAVELETS[wid];
     int F = wv->F;
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
     int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
-    for (int l = 1; l <= L; l++)
-        if (hs[l - 1] < F || ws[l - 1] < F) return -3;
+    /* (inputs shorter than the filter take the same order of additions: checked against PyWavelets, tests/golden) */
     float lo[32], hi[32];
     for (int j = 0; j < F; j++) { lo[j] = (float)wv->dec_lo[j]; hi[j] = (float)wv->dec_hi[j]; }
     memset(arr, 0, sizeof(float) * c * eh * ew);

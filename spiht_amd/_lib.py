@@ -48,6 +48,8 @@ SYMBOLS = [
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
+    "spiht_pipeline_create", "spiht_pipeline_create_on", "spiht_pipeline_destroy", "spiht_pipeline_info", "spiht_pipeline_set_color3", "spiht_pipeline_submit",
+    "spiht_pipeline_submit_gather", "spiht_pipeline_flush", "spiht_pipeline_synchronize", "spiht_pipeline_contexts",
     "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
 ]
 
@@ -146,6 +148,17 @@ def lib():
         L.spiht_l1_flags_words.argtypes = [i64, i64, i64, i32, i32, C.POINTER(u64)]
         L.spiht_decode_lists_flags_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, vp, vp]
         L.spiht_dequant_idwt_flags_batch_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_pipeline_create.argtypes = [i32, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, C.POINTER(vp)]
+        L.spiht_pipeline_create_on.argtypes = [vp, i32, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, C.POINTER(vp)]
+        L.spiht_pipeline_destroy.argtypes = [vp]
+        L.spiht_pipeline_destroy.restype = None
+        L.spiht_pipeline_info.argtypes = [vp, C.POINTER(u64), C.POINTER(i64), C.POINTER(i64)]
+        L.spiht_pipeline_set_color3.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_double]
+        L.spiht_pipeline_submit.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.spiht_pipeline_submit_gather.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32]
+        L.spiht_pipeline_flush.argtypes = [vp]
+        L.spiht_pipeline_synchronize.argtypes = [vp]
+        L.spiht_pipeline_contexts.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
         L.spiht_ctx_lock.argtypes = [vp]
         L.spiht_ctx_unlock.argtypes = [vp]
         _lib = L
@@ -179,9 +192,20 @@ class Context:
         self.handle = h
         self.device = int(device)
 
+    @classmethod
+    def borrowed(cls, handle, device=0):
+        """a view of a context someone else owns (e.g. a pipeline's): never destroyed from here"""
+        self = cls.__new__(cls)
+        self._lib = lib()
+        self.handle = handle if isinstance(handle, C.c_void_p) else C.c_void_p(handle)
+        self.device = int(device)
+        self._borrowed = True
+        return self
+
     def close(self):
         if getattr(self, "handle", None):
-            self._lib.spiht_ctx_destroy(self.handle)
+            if not getattr(self, "_borrowed", False):
+                self._lib.spiht_ctx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

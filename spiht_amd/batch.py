@@ -384,3 +384,67 @@ class OverlappedCodec:
         for Lc in self.Ls:
             Lc.synchronize()
         self.H.synchronize()
+
+
+class Pipeline:
+    """The pipelined round trip as the C ABI offers it (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): the schedule
+    of OverlappedCodec's defaults, queued by the library itself on three contexts it owns -- what a caller in any host
+    language gets, and what bench.py times.  `codec` gives geometry and settings (its context is not used)."""
+
+    def __init__(self, codec, B, own_context=False):
+        """own_context: the HBM-bound passes on a context of the pipeline's own instead of the codec's (one more HIP stream;
+        a process has few hardware queues for them)"""
+        self.codec, self.B = codec, int(B)
+        self.L = codec.L
+        h = C.c_void_p()
+        args = (codec.ctx.device, self.B, codec.c, codec.H, codec.W, codec.wid, codec.mid, codec._lv,
+                float(codec.settings.quantization_scale), codec._mults_p, 0 if codec.max_bits >= 2 ** 63 else codec.max_bits, C.byref(h))
+        if own_context:
+            _lib.check(self.L.spiht_pipeline_create(*args))
+        else:
+            _lib.check(self.L.spiht_pipeline_create_on(codec.ctx.handle, *args))
+        self.handle = h
+        ss = C.c_uint64()
+        _lib.check(self.L.spiht_pipeline_info(self.handle, C.byref(ss), None, None))
+        assert ss.value == codec.slot_stride or codec.max_bits >= 2 ** 63, (ss.value, codec.slot_stride)
+        self.slot_stride = int(ss.value)
+        cm = codec.settings.color_model
+        if cm not in (None, "RGB"):
+            Af, Mf, pf = color_models._params("RGB", cm)
+            Ai, Mi, pi = color_models._params(cm, "RGB")
+            vp = C.c_void_p
+            _lib.check(self.L.spiht_pipeline_set_color3(self.handle, vp(Af.ctypes.data), vp(Mf.ctypes.data), pf, vp(Ai.ctypes.data),
+                                                        vp(Mi.ctypes.data), pi))
+
+    def contexts(self):
+        """[H, L0, L1] as borrowed Context objects (stage timing)"""
+        hs = [C.c_void_p() for _ in range(3)]
+        _lib.check(self.L.spiht_pipeline_contexts(self.handle, *[C.byref(x) for x in hs]))
+        return [_lib.Context.borrowed(x, self.codec.ctx.device) for x in hs]
+
+    def submit(self, d_img, d_out, d_nbits, d_max_n, d_img_out, comm=None, gathered=None, rank=0):
+        """queue one step (device pointers as ints).  comm + gathered = (d_all_slots, d_all_nbits, d_all_max_n): the streams are
+        all-gathered between encoder and decoder and the decoder reads this rank's rows of the gathered buffers"""
+        vp = C.c_void_p
+        if comm is None:
+            _lib.check(self.L.spiht_pipeline_submit(self.handle, vp(d_img), vp(d_out), vp(d_nbits), vp(d_max_n), vp(d_img_out)))
+        else:
+            _lib.check(self.L.spiht_pipeline_submit_gather(self.handle, vp(d_img), vp(d_out), vp(d_nbits), vp(d_max_n), vp(d_img_out),
+                                                           comm.handle, vp(gathered[0]), vp(gathered[1]), vp(gathered[2]), int(rank)))
+
+    def flush(self):
+        _lib.check(self.L.spiht_pipeline_flush(self.handle))
+
+    def synchronize(self):
+        _lib.check(self.L.spiht_pipeline_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.spiht_pipeline_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1048,11 +1048,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
     const bool emit_on = ctx->opt_d1_emit;
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
-    if (f32) {
-        if (ig.L == 0) return SPIHT_ERR_ARG;
-        for (int l = 1; l <= ig.L; l++)
-            if (ig.hs[l - 1] < wv.F || ig.ws[l - 1] < wv.F) return SPIHT_ERR_ARG;
-    }
+    if (f32 && ig.L == 0) return SPIHT_ERR_ARG;
     bool color = ctx->color_on && c == 3;
     if (color && f32) return SPIHT_ERR_ARG;  // the colour model change is float64 (as colour-science's)
     if (f32 && mode >= SPIHT_MODE_SMOOTH) return SPIHT_ERR_ARG;  // (single precision: the five index-map modes only)

@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
     else { o = (int)(r / a.n_lines); line = (int)(r - (size_t)o * a.n_lines); }
     const double *x = a.in + (size_t)plane * a.plane_in + (size_t)line * a.sl;
     const int i = 2 * o + 1;
-    const int jb = (i >= a.N && a.N >= a.F && a.mode != 5) ? i - a.N : -1;
+    const int jb = (i >= a.N && a.mode != 5) ? i - a.N : -1;
     double sa = 0.0, sd = 0.0;
     for (int s2 = 0; s2 < a.F; s2++) {
         const int j = s2 <= jb ? jb - s2 : s2;
@@ -1498,8 +1498,8 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         constexpr int SW = (256 - (F - 2)) / 2;
         int z = 0;
         while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
-        if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
-        if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
+        if (a.mode != 4) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
+        if (a.mode != 4) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
         const uint32_t gx = (uint32_t)((a.out_w + SW - 1) / SW), gy = (uint32_t)((a.out_h + C1_ROWS - 1) / C1_ROWS);
         hipLaunchKernelGGL((k_dwt1_color<F, LOM, HIM>), dim3(gx * gy * (uint32_t)(planes / 3)), dim3(256), 0, st, a, gx, gy);
         return (int)hipGetLastError();
@@ -1513,14 +1513,15 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         return (int)hipGetLastError();
     }
 #endif
-    // Outputs summed in PyWavelets' overhang order: those with jb = 2o+1-N >= 0 on an axis whose input is at least as
-    // long as the filter (constant-edge mode keeps ascending order; shorter inputs go through another loop of pywt's).
+    // Outputs summed in PyWavelets' overhang order: those with jb = 2o+1-N >= 0 (constant-edge mode keeps ascending order).
+    // Inputs shorter than the filter take the same order -- right-hand extension taps first, nearest first, then ascending
+    // through the signal and on into the left-hand extension (checked against PyWavelets: tests/golden/short_pywt.npz).
     // The order is tap jb, jb-1, ..., 0, jb+1, ...: with z leading taps that are zero in both filters it gives the same
     // bits as ascending order until jb >= z+2 (a zero tap adds nothing and the first two non-zero terms commute).
     int z = 0;
     while (z < F && a.lo[z] == 0.0 && a.hi[z] == 0.0) z++;
-    if (a.mode != 4 && a.in_h >= F) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
-    if (a.mode != 4 && a.in_w >= F) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
+    if (a.mode != 4) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
+    if (a.mode != 4) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
     const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
     if (a.dmsb) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     else hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
@@ -1598,8 +1599,8 @@ extern "C" void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv) {
     int z = 0;
     while (z < a->F && a->lo[z] == 0.0 && a->hi[z] == 0.0) z++;
     int ov_h = a->out_h, ov_w = a->out_w;
-    if (a->mode != 4 && a->in_h >= a->F) ov_h = min(a->out_h, (a->in_h + z + 2) / 2);
-    if (a->mode != 4 && a->in_w >= a->F) ov_w = min(a->out_w, (a->in_w + z + 2) / 2);
+    if (a->mode != 4) ov_h = min(a->out_h, (a->in_h + z + 2) / 2);
+    if (a->mode != 4) ov_w = min(a->out_w, (a->in_w + z + 2) / 2);
     cv->on = 1;
     cv->off_h = a->off_h; cv->off_w = a->off_w;
     cv->lim_h = ov_h; cv->lim_w = ov_w;

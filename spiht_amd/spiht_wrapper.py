@@ -160,16 +160,8 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
     # quantised in single precision, wrapper:163-172), everything else in double
     f32 = image.dtype in (np.float32, np.float16)
     img = np.ascontiguousarray(image, dtype=np.float32 if f32 else np.float64)
-    if f32:
-        F = _filter_len(spiht_settings.wavelet)
-        hh, ww = h, w
-        for _ in range(g["level"]):
-            if hh < F or ww < F:
-                raise ValueError("float32 pixels with a level above pywt.dwt_max_level are not supported "
-                                 "(PyWavelets uses a different summation loop there); pass float64 pixels")
-            hh, ww = (hh + F - 1) // 2, (ww + F - 1) // 2
-        if g["level"] == 0:
-            raise ValueError("float32 pixels with level 0 are not supported; pass float64 pixels")
+    if f32 and g["level"] == 0:
+        raise ValueError("float32 pixels with level 0 are not supported; pass float64 pixels")
     bound = C.c_uint64()
     _lib.check(L.spiht_encode_bound(c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], 0x3FFFFFFF, max_bits,
                                     C.byref(bound)))

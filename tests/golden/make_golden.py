@@ -397,6 +397,39 @@ def part_modes():
     print("wrote modes_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
 
 
+def part_short():
+    """inputs SHORTER than the filter (levels above pywt.dwt_max_level: PyWavelets warns and transforms them all the same,
+    and so does the reference, spiht_wrapper.py:163): one and two levels, all eight extension modes in float64, the five
+    index-map modes in float32 as well -> short_pywt.npz (coefficient arrays, every bit)"""
+    import pywt
+    rng = np.random.default_rng(1)
+    out = {"pywt_version": np.array(pywt.__version__)}
+    i = 0
+    for wv in ["bior2.2", "bior6.8", "db4"]:
+        F = pywt.Wavelet(wv).dec_len
+        for mode in ["reflect", "symmetric", "periodic", "zero", "constant", "smooth", "antisymmetric", "antireflect"]:
+            for k, (H, W) in enumerate([(F - 1, F + 3), (F // 2, 2 * F), (3, F - 2), (2, 5), (F + 5, F - 3)]):
+                if H < 2 or W < 2:
+                    continue
+                img = rng.random((1 + k % 2, H, W))
+                for dt in (np.float64, np.float32):
+                    if dt == np.float32 and mode in ("smooth", "antisymmetric", "antireflect"):
+                        continue
+                    lv = 1 + k % 2
+                    arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img.astype(dt), wv, mode=mode, level=lv), axes=(-2, -1))
+                    assert arr.dtype == dt
+                    p = "c%d_" % i
+                    out[p + "img"] = img.astype(dt)
+                    out[p + "arr"] = arr
+                    out[p + "wavelet"] = np.array(wv)
+                    out[p + "mode"] = np.array(mode)
+                    out[p + "level"] = np.array(lv)
+                    i += 1
+    out["ncases"] = np.array(i)
+    np.savez_compressed(os.path.join(HERE, "short_pywt.npz"), **out)
+    print("wrote short_pywt.npz:", i, "cases; pywt", pywt.__version__)
+
+
 if __name__ == "__main__":
     {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32,
-     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes}[sys.argv[1]]()
+     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes, "short": part_short}[sys.argv[1]]()

@@ -68,3 +68,28 @@ def test_bench_under_a_launcher_gathers_through_rccl():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["check"]["gather_rows_match"] is None and "failed" in d["config"]["gather"] and d["value"] > 0
+
+
+def test_two_ranks_on_one_gpu_without_rccl():
+    """`python bench.py --gpus 2` from a bare shell: the process starts its two rank processes itself (before anything
+    touches a GPU), they find each other over the host channel (HostGroup: barrier, maximum of the times), each codes ITS
+    shard -- images with seeds 1000 + rank * B + i -- and rank 0 prints the one line with n_gpus = 2.  RCCL refuses two
+    ranks on one device, so the rehearsal on this one-GPU box runs with the gather switched off (SPIHT_BENCH_NO_RCCL) and
+    both ranks on device 0: the line must say that no gather took place.  What the driver's 8-GPU run adds to this is
+    ncclCommInitRank and the all-gather themselves, rehearsed with one rank in the test above."""
+    env = dict(os.environ, SPIHT_BENCH_NO_RCCL="1", SPIHT_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4",
+                        "--cpu-sample", "0"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["images_per_gpu"] == 4
+    # whole-job throughput: both ranks' images over the slower rank's time
+    assert abs(d["value"] - 2 * 4 * 1920 * 1080 / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-3
+    g = d["config"]["gather"]
+    assert "failed" in g and "SPIHT_BENCH_NO_RCCL" in g["failed"] and "no stream gather" in g["note"]
+    assert d["check"]["gather_rows_match"] is None and d["check"]["nbits_all_equal_budget"] and d["cpu_baseline"] is None
+    assert "RCCL communicator not available" in p.stderr  # every rank says so on stderr

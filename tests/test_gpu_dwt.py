@@ -455,9 +455,72 @@ def test_computed_extension_modes(oracle):
         # with a colour model: the change runs as a pass of its own in front of the two-pass level
         sc = spiht_amd.SpihtSettings(mode=mode, quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
         e2 = spiht_amd.encode_image(imgs[1], sc, 3, 20000)
+        from spiht_amd import _lib, color_models
+        from spiht_amd.batch import DeviceArray
+        ctx = _lib.default_context()
+        d = DeviceArray(ctx, imgs[1].shape, np.float64)
+        d.upload(imgs[1])
+        color_models.device_convert(ctx, d.ptr, 1, 131 * 203, "RGB", "IPT")   # the same kernel, as a call of its own
+        ctx.synchronize()
+        s_plain = spiht_amd.SpihtSettings(mode=mode, quantization_scale=1.0, per_channel_quant_scales=[50.0, 15.0, 15.0])
+        e3 = spiht_amd.encode_image(d.download(), s_plain, 3, 20000)
+        d.free()
+        assert e2.encoded_bytes == e3.encoded_bytes and e2.max_n == e3.max_n, mode
         d2 = spiht_amd.decode_image(e2, sc)
-        assert np.abs(d2[:, :131, :203] - imgs[1]).mean() < 0.1
+        # (a loose bound: at this small budget the extrapolated borders of "smooth" cost most of the bits -- start plane 11
+        # instead of 8 -- and the CPU oracle gives the same 0.19 mean error for it, 0.05 with the default mode)
+        assert np.abs(d2[:, :131, :203] - imgs[1]).mean() < 0.25
     with pytest.raises(ValueError):
         spiht_amd.encode_image(imgs[0], spiht_amd.SpihtSettings(mode="nonsense"), 2)
     with pytest.raises(ValueError):  # single precision: the index-map modes only
         spiht_amd.encode_image(imgs[0].astype(np.float32), spiht_amd.SpihtSettings(mode="smooth"), 2)
+
+
+def _gpu_dwt_f32(img, wavelet, mode, level, q):
+    from spiht_amd import _lib
+    ctx, L = _lib.default_context(), _lib.lib()
+    img = np.ascontiguousarray(img, np.float32)
+    B, c, H, W = img.shape
+    wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
+    v = [C.c_int64() for _ in range(6)]
+    lv = C.c_int()
+    _lib.check(L.spiht_geometry(H, W, wid, level, C.byref(lv), *[C.byref(t) for t in v]))
+    out = np.empty((B, c, v[2].value, v[3].value), np.int32)
+    d_in, d_out = ctx.alloc(img.nbytes), ctx.alloc(out.nbytes)
+    try:
+        ctx.upload(d_in, img)
+        _lib.check(L.spiht_dwt_quant_batch_f32(ctx.handle, C.c_void_p(d_in), B, c, H, W, wid, mid, level, float(q), None, C.c_void_p(d_out)))
+        ctx.download(out, d_out)
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+    return out
+
+
+def test_inputs_shorter_than_the_filter(oracle):
+    """Levels above pywt.dwt_max_level (the reference only warns, spiht_wrapper.py:163): the quantised arrays the GPU makes
+    of inputs shorter than the filter against PyWavelets 1.1.1 (tests/golden/short_pywt.npz; q = 1000 so that the last
+    bits of the coefficients decide) in float64 and float32, and a whole float32 image through encode_image at a level
+    three above the maximum."""
+    import spiht_amd
+    from test_oracle import short_cases
+    n = 0
+    for cs in short_cases():
+        q = 1000.0
+        if cs["img"].dtype == np.float32:
+            got = _gpu_dwt_f32(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], q)[0]
+            want = (cs["arr"] * np.float32(q)).astype(np.int32)
+        else:
+            got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], q, None)[0]
+            want = (cs["arr"] * q).astype(np.int32)
+        bad = np.argwhere(got != want)
+        assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, str(cs["img"].dtype), len(bad), bad[:3])
+        n += 1
+    assert n == 195
+    img = synth_image(5, 3, 40, 56).astype(np.float32)
+    s = spiht_amd.SpihtSettings(wavelet="bior6.8")
+    enc = spiht_amd.encode_image(img, s, level=4, max_bits=30000)   # pywt.dwt_max_level(40, 18) = 1
+    arr, _ = oracle.wavedec2_array_f32(img, "bior6.8", "reflect", 4)
+    g = oracle.geometry(40, 56, "bior6.8", 4)
+    ref_bytes, ref_n = oracle.encode(oracle.quantize_f32(arr, 50.0), g["ll_h"], g["ll_w"], 30000)[:2]
+    assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n

@@ -412,3 +412,24 @@ def test_computed_extension_modes_match_pywt(oracle):
         assert np.array_equal(back.view(np.uint64), cs["rec_img"].view(np.uint64))
         n += 1
     assert n == 30
+
+
+def short_cases():
+    z = np.load(os.path.join(GOLD, "short_pywt.npz"))
+    for i in range(int(z["ncases"])):
+        p = "c%d_" % i
+        yield dict(img=z[p + "img"], arr=z[p + "arr"], wavelet=str(z[p + "wavelet"]), mode=str(z[p + "mode"]), level=int(z[p + "level"]))
+
+
+def test_inputs_shorter_than_the_filter_match_pywt(oracle):
+    """Levels above pywt.dwt_max_level: PyWavelets warns and transforms (and so does the reference, spiht_wrapper.py:163).
+    The oracle against PyWavelets 1.1.1 on inputs shorter than the filter (tests/golden/short_pywt.npz), every bit of the
+    coefficient arrays: eight extension modes in float64, the five index maps in float32."""
+    n = {"float64": 0, "float32": 0}
+    for cs in short_cases():
+        f = oracle.wavedec2_array_f32 if cs["img"].dtype == np.float32 else oracle.wavedec2_array
+        arr, _ = f(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
+        assert arr.dtype == cs["arr"].dtype and arr.shape == cs["arr"].shape
+        assert np.array_equal(arr.view(np.uint8), cs["arr"].view(np.uint8)), (cs["wavelet"], cs["mode"], cs["img"].shape, cs["img"].dtype)
+        n[str(arr.dtype)] += 1
+    assert n["float64"] >= 100 and n["float32"] >= 60

@@ -15,20 +15,28 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256  # the bench's launch size
 ITERS = 2
 
 
-def counters(stage, kernel):
+OCC = {}  # stage run -> fraction of occupied level-1 tiles printed by prof_stage.py idwtf
+
+
+def counters(stage, kernel, bpp=None):
     """per counter: {(kernel name, grid size): mean counter value per launch} of the launches of the kernels whose name
     contains `kernel` in a run of `stage`"""
     res = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         env = dict(os.environ, TMPDIR="/tmp")
-        subprocess.check_call(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-                               "python3", os.path.join(ROOT, "tools", "prof_stage.py"), stage, str(B), str(ITERS)],
-                              cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if bpp is not None:
+            env["PROF_BPP"] = str(bpp)
+        txt = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                              "python3", os.path.join(ROOT, "tools", "prof_stage.py"), stage, str(B), str(ITERS)],
+                             cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+        for ln in txt.splitlines():
+            if ln.startswith("occupied_tiles_fraction"):
+                OCC[(stage, bpp)] = float(ln.split()[1])
         by = {}
         for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             for r in csv.DictReader(open(p)):
@@ -56,6 +64,21 @@ def level1(c):
 
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None  # "idwtf": only the inverse level 1 with occupancy words, into the committed file
+if ONLY == "idwtf":
+    other = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_other.json")))
+    assert other["images_per_launch"] == B
+    other["idwt_level1_with_occupancy_words"] = {}
+    for bpp in (0.1, 0.5, 1.0):
+        c = counters("idwtf", "false, true>", bpp)
+        rd, wr = bytes_of(c, level1(c))
+        other["idwt_level1_with_occupancy_words"]["%g bpp" % bpp] = {
+            "occupied_tiles_fraction": OCC.get(("idwtf", bpp)), "read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B,
+            "hbm_bytes_per_image": (rd + wr) / B,
+            "algorithmic_bytes_per_image_all_tiles_empty": 3 * (1080 * 1920 * 8 + 542 * 962 * 8)}
+    json.dump(other, open(os.path.join(ROOT, "gpurun_out", "hbm_traffic_other.json"), "w"), indent=1)
+    print(json.dumps(other))
+    sys.exit(0)
 # forward level 1: the largest grid of k_dwt_level and of the overhang fix-up kernel behind it (k_dwt_edge)
 c = counters("dwt", "k_dwt_")
 k1 = level1(c)
@@ -74,6 +97,16 @@ if not c["FETCH_SIZE"]:
 rd, wr = bytes_of(c, level1(c))
 other["idwt_level1"] = {"read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B, "hbm_bytes_per_image": (rd + wr) / B,
                         "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
+# ... and with the decoder's occupancy words (the default of the image-level calls): the detail bands of empty tiles are not
+# read, so the read side depends on the bit rate
+other["idwt_level1_with_occupancy_words"] = {}
+for bpp in (0.1, 0.5, 1.0):
+    c = counters("idwtf", "false, true>", bpp)  # the instantiation of the persistent kernel that reads the words: level 1 only
+    rd, wr = bytes_of(c, level1(c))
+    other["idwt_level1_with_occupancy_words"]["%g bpp" % bpp] = {
+        "occupied_tiles_fraction": OCC.get(("idwtf", bpp)), "read_bytes_per_image": rd / B, "write_bytes_per_image": wr / B,
+        "hbm_bytes_per_image": (rd + wr) / B,
+        "algorithmic_bytes_per_image_all_tiles_empty": 3 * (1080 * 1920 * 8 + 542 * 962 * 8)}
 c = counters("pyramid", "k_pyr_")  # k_pyr_12 (depths 1 and 2), k_pyr_round (deeper rounds), k_pyr_ll (root block)
 rd, wr = bytes_of(c, list(c["FETCH_SIZE"]))
 n_coef, n_par = 3 * 1111 * 1949, 3 * (1111 // 2) * (1949 // 2)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Run one stage of the hot path in a loop (for rocprofv3 --pmc / --kernel-trace runs).
-usage: prof_stage.py {dwt|idwt|pyramid|encode|decode|all} [batch] [iters]"""
+usage: prof_stage.py {dwt|idwt|idwtf|pyramid|encode|decode|all} [batch] [iters]
+idwtf: the inverse transform reading the decoder's level-1 occupancy words (the default of the image-level calls); PROF_BPP
+in the environment: bits per pixel of the streams (default: the bench's)."""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +11,7 @@ from spiht_amd import _lib
 from spiht_amd.batch import BatchCodec, DeviceArray
 from spiht_amd.spiht_wrapper import SpihtSettings
 from bench import synth_image, H, W, C_IMG, LEVEL, BPP
+BPP = float(os.environ.get("PROF_BPP", BPP))
 
 stage = sys.argv[1] if len(sys.argv) > 1 else "all"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
@@ -38,6 +41,16 @@ codec.nbits_to_nbytes(d_nbits.ptr, B, d_nbytes.ptr)
 _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B, C_IMG,
                                     g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], vp(d_rec.ptr)))
 ctx.synchronize()
+d_fl = None
+if stage == "idwtf":
+    nw = C.c_uint64()
+    _lib.check(L.spiht_l1_flags_words(C_IMG, H, W, codec.wid, LEVEL, C.byref(nw)))
+    d_fl = DeviceArray(ctx, (B, nw.value), np.uint32)
+    ctx.memset(d_rec.ptr, 0, d_rec.nbytes)
+    _lib.check(L.spiht_decode_lists_flags_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B,
+                                                    C_IMG, H, W, codec.wid, LEVEL, vp(d_rec.ptr), vp(d_fl.ptr)))
+    ctx.synchronize()
+    print("occupied_tiles_fraction %.5f" % float(d_fl.download().mean()))
 for _ in range(iters):
     if stage in ("dwt", "all"):
         _lib.check(L.spiht_dwt_quant_batch_f64(ctx.handle, vp(d_img.ptr), B, C_IMG, H, W, codec.wid, codec.mid, LEVEL, 50.0, None, vp(d_co.ptr)))
@@ -47,6 +60,8 @@ for _ in range(iters):
         _lib.check(L.spiht_encode_batch_i32(ctx.handle, vp(d_co.ptr), B, C_IMG, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], int(H * W * BPP), vp(d_out.ptr), codec.slot_stride, vp(d_nbits.ptr), vp(d_maxn.ptr)))
     if stage in ("decode", "all"):
         _lib.check(L.spiht_decode_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B, C_IMG, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], vp(d_rec.ptr)))
+    if stage == "idwtf":
+        _lib.check(L.spiht_dequant_idwt_flags_batch_f64(ctx.handle, vp(d_rec.ptr), vp(d_fl.ptr), B, C_IMG, H, W, codec.wid, codec.mid, LEVEL, 50.0, None, vp(d_img2.ptr)))
     if stage in ("idwt", "all"):
         _lib.check(L.spiht_dequant_idwt_batch_f64(ctx.handle, vp(d_rec.ptr), B, C_IMG, H, W, codec.wid, codec.mid, LEVEL, 50.0, None, vp(d_img2.ptr)))
 ctx.synchronize()
