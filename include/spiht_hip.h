@@ -36,7 +36,10 @@ enum {
 enum { SPIHT_MODE_REFLECT = 0, SPIHT_MODE_SYMMETRIC = 1, SPIHT_MODE_PERIODIC = 2, SPIHT_MODE_ZERO = 3,
        SPIHT_MODE_CONSTANT = 4,
        /* the modes whose extended samples are computed, not picked: a slower two-pass forward transform, float64 pixels */
-       SPIHT_MODE_SMOOTH = 5, SPIHT_MODE_ANTISYMMETRIC = 6, SPIHT_MODE_ANTIREFLECT = 7 };
+       SPIHT_MODE_SMOOTH = 5, SPIHT_MODE_ANTISYMMETRIC = 6, SPIHT_MODE_ANTIREFLECT = 7,
+       /* another length rule: ceil(n / 2) coefficients per level, 2 n samples back (spiht_geometry_mode); two-pass in both
+        * directions, float64 pixels */
+       SPIHT_MODE_PERIODIZATION = 8 };
 
 #define SPIHT_MAX_BITS_UNLIMITED 0xFFFFFFFFFFFFFFFFull
 
@@ -149,9 +152,12 @@ int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_
  * PyWavelets by tools/gen_wavelets.py).  Ids are positions in that table: bior2.2 = 0, bior4.4 = 1, bior6.8 = 2, haar = 3. */
 int spiht_wavelet_id(const char *name);           /* < 0 if unknown (or longer than 20 taps) */
 int spiht_wavelet_taps(int wavelet);              /* filter length (pywt dec_len); < 0: no such id */
-int spiht_mode_id(const char *name);              /* the pywt names of the modes above; <0 if unknown ("periodization": not built) */
+int spiht_mode_id(const char *name);              /* the pywt names of the nine modes above; <0 if unknown */
 int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h, int64_t *ll_w,
                    int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W);
+/* ... for an extension mode: periodization has its own sizes (pywt.dwt_coeff_len), every other mode those above */
+int spiht_geometry_mode(int64_t H, int64_t W, int wavelet, int mode, int level, int *level_used, int64_t *ll_h, int64_t *ll_w,
+                        int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W);
 
 /* d_img: float64 [B,c,H,W] (device).  channel_mults: HOST array of c doubles or NULL
  * (SpihtSettings.per_channel_quant_scales); q_scale: SpihtSettings.quantization_scale.
@@ -236,14 +242,15 @@ int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, int64_t B, i
  * decoded cell, and level 1 of the inverse transform does not read the detail bands of a tile whose word is zero (zeros go
  * through the same arithmetic: the same bits).  The image-level decode calls do this internally (option "l1_flags");
  * the split calls take the words explicitly:
- *   spiht_l1_flags_words                 words per image for this geometry (0: not applicable -- fewer than two levels)
+ *   spiht_l1_flags_words                 words per image for this geometry (0: not applicable -- fewer than two levels,
+ *                                        periodization)
  *   spiht_decode_lists_flags_batch_i32   spiht_decode_lists_batch_i32 for the arrays of H x W images + the words
  *                                        (zero-filled by the call; d_flags NULL: no flags)
  *   spiht_dequant_idwt_flags_batch_f64   spiht_dequant_idwt_batch_f64 reading them (d_flags NULL: reads everything) */
-int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int level, uint64_t *words_per_image);
+int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level, uint64_t *words_per_image);
 int spiht_decode_lists_flags_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride, const uint64_t *d_nbytes,
                                        const uint8_t *d_max_n, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet,
-                                       int level, int32_t *d_out_zeroed, uint32_t *d_flags);
+                                       int mode, int level, int32_t *d_out_zeroed, uint32_t *d_flags);
 int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const uint32_t *d_flags, int64_t B, int64_t c,
                                        int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
                                        const double *channel_mults, double *d_img_out);

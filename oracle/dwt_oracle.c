@@ -46,7 +46,9 @@ static const wavelet_t WAVELETS[] = {
 /* modes: 0 reflect, 1 symmetric, 2 periodic, 3 zero, 4 constant */
 enum { MODE_REFLECT = 0, MODE_SYMMETRIC = 1, MODE_PERIODIC = 2, MODE_ZERO = 3, MODE_CONSTANT = 4,
        /* ... and the extension modes of PyWavelets that are not index maps: the extended sample is computed */
-       MODE_SMOOTH = 5, MODE_ANTISYMMETRIC = 6, MODE_ANTIREFLECT = 7 };
+       MODE_SMOOTH = 5, MODE_ANTISYMMETRIC = 6, MODE_ANTIREFLECT = 7,
+       /* ... and periodization: another length rule (ceil(N / 2) coefficients, 2 L samples back) and its own alignment */
+       MODE_PERIODIZATION = 8 };
 
 int orc_wavelet_id(const char *name) {
     for (int i = 0; i < NWAVELETS; i++)
@@ -96,6 +98,14 @@ int orc_geometry(int64_t H, int64_t W, int F, int level, int64_t *hs, int64_t *w
     for (int l = L; l >= 1; l--) { ah += hs[l]; aw += ws[l]; }
     *enc_h = ah; *enc_w = aw;
     return L;
+}
+
+/* ... for an extension mode: periodization keeps ceil(N / 2) coefficients per level -- the rule above with a two-tap
+ * filter -- while the level count still follows the real filter length (pywt.dwt_max_level knows no mode) */
+int orc_geometry_mode(int64_t H, int64_t W, int F, int mode, int level, int64_t *hs, int64_t *ws, int64_t *ll_h, int64_t *ll_w,
+                      int64_t *enc_h, int64_t *enc_w) {
+    const int L = orc_resolve_level(H, W, F, level);
+    return orc_geometry(H, W, mode == MODE_PERIODIZATION ? 2 : F, L, hs, ws, ll_h, ll_w, enc_h, enc_w);
 }
 
 /* signal extension index map; returns -1 for "zero" */
@@ -196,6 +206,56 @@ static void dwt_line(const double *x, int64_t N, int64_t sx, const double *lo, c
     }
 }
 
+/* Periodization (pywt downsampling_convolution_periodization): the signal, made even by repeating its last sample, is
+ * extended periodically; output o = sum_j f[j] xe[F/2 + 2o - j], o < ceil(N / 2).  Order of the additions as everywhere in
+ * that file: ascending taps, except that where the window hangs over the right end the taps that read beyond it come
+ * first, nearest first. */
+static void dwt_line_per(const double *x, int64_t N, int64_t sx, const double *lo, const double *hi, int F, double *ca,
+                         double *cd, int64_t so) {
+    const int64_t L = (N + 1) / 2, Np = N + (N & 1);
+    for (int64_t o = 0; o < L; o++) {
+        double a = 0.0, d = 0.0;
+        const int64_t i = F / 2 + 2 * o, jb = i >= N ? i - N : -1;
+        for (int s = 0; s < F; s++) {
+            const int j = s <= jb ? (int)(jb - s) : s;
+            int64_t m = (i - j) % Np;
+            if (m < 0) m += Np;
+            const double v = x[(m < N ? m : N - 1) * sx];
+            a += lo[j] * v;
+            d += hi[j] * v;
+        }
+        ca[o * so] = a;
+        cd[o * so] = d;
+    }
+}
+/* ... and back (upsampling_convolution_valid_sf_periodization): 2 L samples, x[n] = sum_k rec[n - 2k + F/2 - 1] c[k mod L],
+ * i.e. with p = (n + F/2 - 1) & 1 and i = (n + F/2 - 1 - p) / 2 the terms j = 0 .. F/2-1: tap 2j + p against c[(i - j) mod L].
+ * pywt adds every product straight into the output sample, the approximation's first, then the detail's. */
+static void idwt_line_per(const double *ca, const double *cd, int64_t L, int64_t si, const double *lo, const double *hi, int F,
+                          double *x, int64_t so) {
+    const int64_t s0 = F / 2 - 1;
+    for (int64_t n = 0; n < 2 * L; n++) {
+        const int p = (int)((n + s0) & 1);
+        const int64_t i = (n + s0 - p) / 2;
+        /* where the window hangs over the right end (i >= L) the terms beyond it come first, nearest first -- and sample 0
+         * of a filter with an even number of tap PAIRS is computed by pywt together with sample 2L-1, as the odd half of
+         * that window (i = L + F/4 - 1) */
+        int64_t jb = i >= L ? i - L : -1;
+        if (n == 0 && (F / 2) % 2 == 0) jb = F / 4 - 1;
+        double acc = 0.0;
+        for (int pass = 0; pass < 2; pass++) {
+            const double *c = pass ? cd : ca, *f = pass ? hi : lo;
+            for (int s = 0; s < F / 2; s++) {
+                const int j = s <= jb ? (int)(jb - s) : s;
+                int64_t k = (i - j) % L;
+                if (k < 0) k += L;
+                acc += f[2 * j + p] * c[k * si];
+            }
+        }
+        x[n * so] = acc;
+    }
+}
+
 /* 1-D synthesis along a strided line; output length 2L-F+2.  Order of the additions as in pywt's
  * upsampling_convolution_valid_sf (convolution.template.c): the approximation part and the detail part are two separate
  * sums, each over j = 0..F/2-1 with taps 2j (even outputs) / 2j+1 (odd outputs) against input i-j, and the detail sum is
@@ -222,9 +282,19 @@ static void idwt_line(const double *ca, const double *cd, int64_t L, int64_t si,
 static int dwt2_level(const double *in, int64_t h, int64_t w, const wavelet_t *wv, int mode, double *aa,
                       double *ad, double *da, double *dd) {
     int F = wv->F;
-    int64_t h2 = (h + F - 1) / 2, w2 = (w + F - 1) / 2;
+    const int per = mode == MODE_PERIODIZATION;
+    int64_t h2 = per ? (h + 1) / 2 : (h + F - 1) / 2, w2 = per ? (w + 1) / 2 : (w + F - 1) / 2;
     double *ta = (double *)malloc(sizeof(double) * h2 * w), *td = (double *)malloc(sizeof(double) * h2 * w);
     if (!ta || !td) { free(ta); free(td); return -1; }
+    if (per) {
+        for (int64_t j = 0; j < w; j++) dwt_line_per(in + j, h, w, wv->dec_lo, wv->dec_hi, F, ta + j, td + j, w);
+        for (int64_t i = 0; i < h2; i++) {
+            dwt_line_per(ta + i * w, w, 1, wv->dec_lo, wv->dec_hi, F, aa + i * w2, ad + i * w2, 1);
+            dwt_line_per(td + i * w, w, 1, wv->dec_lo, wv->dec_hi, F, da + i * w2, dd + i * w2, 1);
+        }
+        free(ta); free(td);
+        return 0;
+    }
     for (int64_t j = 0; j < w; j++) dwt_line(in + j, h, w, wv->dec_lo, wv->dec_hi, F, mode, ta + j, td + j, w);
     for (int64_t i = 0; i < h2; i++) {
         dwt_line(ta + i * w, w, 1, wv->dec_lo, wv->dec_hi, F, mode, aa + i * w2, ad + i * w2, 1);
@@ -240,7 +310,7 @@ int orc_wavedec2_array(const double *img, int64_t c, int64_t H, int64_t W, int w
     if (wid < 0 || wid >= NWAVELETS) return -1;
     const wavelet_t *wv = &WAVELETS[wid];
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
-    int L = orc_geometry(H, W, wv->F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int L = orc_geometry_mode(H, W, wv->F, mode, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
     memset(arr, 0, sizeof(double) * c * eh * ew);
     /* band offsets: level l detail block sits at accumulated offset A_l */
     int64_t offh[64], offw[64];
@@ -300,32 +370,41 @@ void orc_dequantize(const int32_t *rec, int64_t c, int64_t n_per_c, const double
 }
 
 /* output image size of waverec2 for (H,W,F,level): sizes follow the trim rule */
-void orc_waverec2_shape(int64_t H, int64_t W, int F, int level, int64_t *Ho, int64_t *Wo) {
+void orc_waverec2_shape_mode(int64_t H, int64_t W, int F, int mode, int level, int64_t *Ho, int64_t *Wo) {
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
-    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int L = orc_geometry_mode(H, W, F, mode, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    const int Fg = mode == MODE_PERIODIZATION ? 2 : F;
     int64_t ah = ll_h, aw = ll_w;
     for (int l = L; l >= 1; l--) {
         if (ah == hs[l] + 1) ah--;
         if (aw == ws[l] + 1) aw--;
-        ah = 2 * hs[l] - F + 2;
-        aw = 2 * ws[l] - F + 2;
+        ah = 2 * hs[l] - Fg + 2;
+        aw = 2 * ws[l] - Fg + 2;
     }
     *Ho = ah; *Wo = aw;
 }
+void orc_waverec2_shape(int64_t H, int64_t W, int F, int level, int64_t *Ho, int64_t *Wo) {
+    orc_waverec2_shape_mode(H, W, F, MODE_REFLECT, level, Ho, Wo);
+}
 
-/* array_to_coeffs + waverec2 : wrapper:275-276.  out is [c,Ho,Wo] from orc_waverec2_shape. */
-int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int wid, int level,
-                       double *out) {
+/* array_to_coeffs + waverec2 : wrapper:275-276.  out is [c,Ho,Wo] from orc_waverec2_shape_mode.  (The extension mode
+ * matters to the way back only when it is periodization.) */
+int orc_waverec2_array_mode(const double *arr, int64_t c, int64_t H, int64_t W, int wid, int mode, int level, double *out);
+int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int wid, int level, double *out) {
+    return orc_waverec2_array_mode(arr, c, H, W, wid, MODE_REFLECT, level, out);
+}
+int orc_waverec2_array_mode(const double *arr, int64_t c, int64_t H, int64_t W, int wid, int mode, int level, double *out) {
     if (wid < 0 || wid >= NWAVELETS) return -1;
     const wavelet_t *wv = &WAVELETS[wid];
+    const int per = mode == MODE_PERIODIZATION;
     int F = wv->F;
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
-    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int L = orc_geometry_mode(H, W, F, mode, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
     int64_t offh[64], offw[64];
     int64_t ah0 = ll_h, aw0 = ll_w;
     for (int l = L; l >= 1; l--) { offh[l] = ah0; offw[l] = aw0; ah0 += hs[l]; aw0 += ws[l]; }
     int64_t Ho, Wo;
-    orc_waverec2_shape(H, W, F, level, &Ho, &Wo);
+    orc_waverec2_shape_mode(H, W, F, mode, level, &Ho, &Wo);
     for (int64_t k = 0; k < c; k++) {
         const double *in = arr + k * eh * ew;
         int64_t ah = ll_h, aw = ll_w;
@@ -338,7 +417,7 @@ int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int w
             /* trim rule (_multilevel.py waverec2): a_len == d_len + 1 -> drop last */
             int64_t uh = (ah == h2 + 1) ? ah - 1 : ah, uw = (aw == w2 + 1) ? aw - 1 : aw;
             if (uh != h2 || uw != w2) { free(a); return -3; }
-            int64_t wo = 2 * w2 - F + 2, ho = 2 * h2 - F + 2;
+            int64_t wo = per ? 2 * w2 : 2 * w2 - F + 2, ho = per ? 2 * h2 : 2 * h2 - F + 2;
             /* axis -1 first: (aa,ad) -> lo rows ; (da,dd) -> hi rows */
             double *tl = (double *)malloc(sizeof(double) * h2 * wo), *th = (double *)malloc(sizeof(double) * h2 * wo);
             double *rowd = (double *)malloc(sizeof(double) * w2 * 3);
@@ -348,11 +427,18 @@ int orc_waverec2_array(const double *arr, int64_t c, int64_t H, int64_t W, int w
                 const double *ad = in + i * ew + offw[l];
                 const double *da = in + (offh[l] + i) * ew;
                 const double *dd = in + (offh[l] + i) * ew + offw[l];
-                idwt_line(a + i * aw, ad, w2, 1, wv->rec_lo, wv->rec_hi, F, tl + i * wo, 1);
-                idwt_line(da, dd, w2, 1, wv->rec_lo, wv->rec_hi, F, th + i * wo, 1);
+                if (per) {
+                    idwt_line_per(a + i * aw, ad, w2, 1, wv->rec_lo, wv->rec_hi, F, tl + i * wo, 1);
+                    idwt_line_per(da, dd, w2, 1, wv->rec_lo, wv->rec_hi, F, th + i * wo, 1);
+                } else {
+                    idwt_line(a + i * aw, ad, w2, 1, wv->rec_lo, wv->rec_hi, F, tl + i * wo, 1);
+                    idwt_line(da, dd, w2, 1, wv->rec_lo, wv->rec_hi, F, th + i * wo, 1);
+                }
             }
-            for (int64_t j = 0; j < wo; j++)
-                idwt_line(tl + j, th + j, h2, wo, wv->rec_lo, wv->rec_hi, F, nx + j, wo);
+            for (int64_t j = 0; j < wo; j++) {
+                if (per) idwt_line_per(tl + j, th + j, h2, wo, wv->rec_lo, wv->rec_hi, F, nx + j, wo);
+                else idwt_line(tl + j, th + j, h2, wo, wv->rec_lo, wv->rec_hi, F, nx + j, wo);
+            }
             free(tl); free(th); free(rowd); free(a);
             a = nx; ah = ho; aw = wo;
         }

@@ -21,7 +21,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 RULE_RUST = 0
 RULE_PY = 1
 
-MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4, "smooth": 5, "antisymmetric": 6, "antireflect": 7}
+MODES = {"reflect": 0, "symmetric": 1, "periodic": 2, "zero": 3, "constant": 4, "smooth": 5, "antisymmetric": 6, "antireflect": 7, "periodization": 8}
 
 
 def build(force=False):
@@ -240,15 +240,16 @@ def wavelet_filters(name):
     return arrs
 
 
-def geometry(H, W, wavelet, level):
-    """-> dict(level, hs, ws, ll_h, ll_w, enc_h, enc_w)   (wrapper:92-139)"""
+def geometry(H, W, wavelet, level, mode="reflect"):
+    """-> dict(level, hs, ws, ll_h, ll_w, enc_h, enc_w)   (wrapper:92-139); the mode matters when it is periodization"""
     wid = wavelet_id(wavelet)
     F = lib().orc_wavelet_len(wid)
     hs = np.zeros(64, dtype=np.int64)
     ws = np.zeros(64, dtype=np.int64)
     v = [C.c_int64() for _ in range(4)]
-    L = lib().orc_geometry(H, W, F, -1 if level is None else int(level), hs.ctypes.data, ws.ctypes.data,
-                           *[C.byref(t) for t in v])
+    lib().orc_geometry_mode.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6
+    L = lib().orc_geometry_mode(H, W, F, MODES[mode], -1 if level is None else int(level), hs.ctypes.data, ws.ctypes.data,
+                                *[C.byref(t) for t in v])
     return dict(level=L, hs=hs[:L + 1].tolist(), ws=ws[:L + 1].tolist(), ll_h=v[0].value, ll_w=v[1].value,
                 enc_h=v[2].value, enc_w=v[3].value)
 
@@ -257,7 +258,7 @@ def wavedec2_array(img, wavelet, mode, level):
     """pywt.wavedec2 + coeffs_to_array (wrapper:163-165) -> float64 [c,enc_h,enc_w]"""
     img = np.ascontiguousarray(img, dtype=np.float64)
     c, H, W = img.shape
-    g = geometry(H, W, wavelet, level)
+    g = geometry(H, W, wavelet, level, mode)
     arr = np.empty((c, g["enc_h"], g["enc_w"]), dtype=np.float64)
     rc = lib().orc_wavedec2_array(img.ctypes.data, c, H, W, wavelet_id(wavelet), MODES[mode],
                                   -1 if level is None else int(level), arr.ctypes.data)
@@ -314,17 +315,21 @@ def dequantize(rec, q, mults=None):
     return out
 
 
-def waverec2_array(arr, H, W, wavelet, level):
-    """pywt.array_to_coeffs + waverec2 (wrapper:275-276) -> float64 [c,H',W']"""
+def waverec2_array(arr, H, W, wavelet, level, mode="reflect"):
+    """pywt.array_to_coeffs + waverec2 (wrapper:275-276) -> float64 [c,H',W']; the mode matters when it is periodization"""
     arr = np.ascontiguousarray(arr, dtype=np.float64)
     c = arr.shape[0]
     wid = wavelet_id(wavelet)
     F = lib().orc_wavelet_len(wid)
     lv = -1 if level is None else int(level)
     Ho, Wo = C.c_int64(), C.c_int64()
-    lib().orc_waverec2_shape(H, W, F, lv, C.byref(Ho), C.byref(Wo))
+    L = lib()
+    L.orc_waverec2_shape_mode.argtypes = [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_waverec2_shape_mode.restype = None
+    L.orc_waverec2_array_mode.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_waverec2_shape_mode(H, W, F, MODES[mode], lv, C.byref(Ho), C.byref(Wo))
     out = np.empty((c, Ho.value, Wo.value), dtype=np.float64)
-    rc = lib().orc_waverec2_array(arr.ctypes.data, c, H, W, wid, lv, out.ctypes.data)
+    rc = L.orc_waverec2_array_mode(arr.ctypes.data, c, H, W, wid, MODES[mode], lv, out.ctypes.data)
     if rc:
         raise RuntimeError("orc_waverec2_array rc=%d" % rc)
     return out
@@ -345,8 +350,9 @@ def encode_image(image, wavelet="bior2.2", mode="reflect", level=None, q=50.0, m
     return data, max_n, g
 
 
-def decode_image(data, max_n, c, H, W, wavelet="bior2.2", level=None, q=50.0, mults=None, rule=RULE_RUST):
-    """CPU restatement of spiht_wrapper.decode_image (wrapper:192-281), no colour conversion."""
-    g = geometry(H, W, wavelet, level)
+def decode_image(data, max_n, c, H, W, wavelet="bior2.2", level=None, q=50.0, mults=None, rule=RULE_RUST, mode="reflect"):
+    """CPU restatement of spiht_wrapper.decode_image (wrapper:192-281), no colour conversion.  (The extension mode matters
+    only when it is periodization.)"""
+    g = geometry(H, W, wavelet, level, mode)
     rec = decode(data, max_n, c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], rule)
-    return waverec2_array(dequantize(rec, q, mults), H, W, wavelet, level)
+    return waverec2_array(dequantize(rec, q, mults), H, W, wavelet, level, mode)

@@ -50,7 +50,7 @@ SYMBOLS = [
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
     "spiht_pipeline_create", "spiht_pipeline_create_on", "spiht_pipeline_destroy", "spiht_pipeline_info", "spiht_pipeline_set_color3", "spiht_pipeline_submit",
     "spiht_pipeline_submit_gather", "spiht_pipeline_flush", "spiht_pipeline_synchronize", "spiht_pipeline_contexts",
-    "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
+    "spiht_geometry_mode", "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
 ]
 
 
@@ -145,8 +145,9 @@ def lib():
         L.spiht_rccl_library.restype = C.c_char_p
         L.spiht_rccl_library.argtypes = []
         L.spiht_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
-        L.spiht_l1_flags_words.argtypes = [i64, i64, i64, i32, i32, C.POINTER(u64)]
-        L.spiht_decode_lists_flags_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, vp, vp]
+        L.spiht_l1_flags_words.argtypes = [i64, i64, i64, i32, i32, i32, C.POINTER(u64)]
+        L.spiht_decode_lists_flags_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]
+        L.spiht_geometry_mode.argtypes = [i64, i64, i32, i32, i32, C.POINTER(i32)] + [C.POINTER(i64)] * 6
         L.spiht_dequant_idwt_flags_batch_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
         L.spiht_pipeline_create.argtypes = [i32, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, C.POINTER(vp)]
         L.spiht_pipeline_create_on.argtypes = [vp, i32, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, C.POINTER(vp)]

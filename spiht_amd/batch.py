@@ -65,7 +65,7 @@ class BatchCodec:
         self.ctx = ctx if ctx is not None else _lib.default_context()
         self.L = _lib.lib()
         self.wid, self.mid = _wavelet_mode_ids(self.settings)
-        self.geom = _geometry(H, W, self.wid, level)
+        self.geom = _geometry(H, W, self.wid, level, self.mid)
         self.max_bits = 99999999999999999 if max_bits is None else int(max_bits)
         self.mults, self._mults_p = _mults_arg(self.settings.per_channel_quant_scales, self.c)
         bound = C.c_uint64()
@@ -255,7 +255,7 @@ class OverlappedCodec:
         self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if self.split else [None, None]
         # occupancy words of the inverse transform's level-1 tiles: decoder -> inverse transform (include/spiht_hip.h)
         nw = C.c_uint64()
-        _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec._lv, C.byref(nw)))
+        _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec.mid, codec._lv, C.byref(nw)))
         self.flags = mk((B, nw.value), np.uint32) if nw.value and l1_flags else [None, None]
         # the coefficient arrays are this object's own and only the forward transform writes them: their zero padding is
         # written once per array, not once per step (beside a list decoder that launch of thin strips took 0.74 ms)
@@ -352,7 +352,7 @@ class OverlappedCodec:
         x_out, x_nbits, x_max_n = dec_src if dec_src is not None else (d_out, d_nbits, d_max_n)
         _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(x_nbits), B, vp(d_nbytes)))
         _lib.check(cd.L.spiht_decode_lists_flags_batch_i32(
-            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, cd.H, cd.W, cd.wid, cd._lv,
+            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
             vp(self.rec[s].ptr), vp(self.flags[s].ptr if self.flags[s] else None)))
         if self.split:  # the coarse levels of this batch's inverse transform, behind its decoder
             _lib.check(cd.L.spiht_idwt_coarse_batch_f64(

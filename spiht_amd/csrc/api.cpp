@@ -35,6 +35,7 @@ int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, c
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double *t_lo, double *t_hi, double *b_aa, double *b_ad, double *b_da,
                                double *b_dd, hipStream_t st);
+int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
                              double q, uint32_t *maxabs, hipStream_t st);
@@ -207,13 +208,18 @@ struct ImgGeom {
     int64_t hs[SPIHT_MAX_LEVELS + 1], ws[SPIHT_MAX_LEVELS + 1];      // band sizes, [0] = image
     int64_t offh[SPIHT_MAX_LEVELS + 1], offw[SPIHT_MAX_LEVELS + 1];  // detail block offsets per level
     int64_t ll_h, ll_w, enc_h, enc_w, rec_H, rec_W;
+    bool per;  // periodization: ceil(n / 2) coefficients per level and 2 n samples back (the rule below with a two-tap filter)
 };
 
-static int img_geometry(int64_t H, int64_t W, int F, int level, ImgGeom *g) {
+// mode: only periodization changes the geometry (pywt.dwt_coeff_len); the level count follows the real filter length whatever
+// the mode (pywt.dwt_max_level knows none)
+static int img_geometry(int64_t H, int64_t W, int F_real, int level, ImgGeom *g, int mode = SPIHT_MODE_REFLECT) {
     if (H < 1 || W < 1) return SPIHT_ERR_ARG;
     int L = level;
-    if (L < 0) L = std::min(dwt_max_level(H, F), dwt_max_level(W, F));
+    if (L < 0) L = std::min(dwt_max_level(H, F_real), dwt_max_level(W, F_real));
     if (L > SPIHT_MAX_LEVELS) return SPIHT_ERR_ARG;
+    g->per = mode == SPIHT_MODE_PERIODIZATION;
+    const int F = g->per ? 2 : F_real;
     g->L = L;
     g->hs[0] = H;
     g->ws[0] = W;
@@ -997,17 +1003,24 @@ extern "C" int spiht_wavelet_taps(int wavelet) {
 }
 extern "C" int spiht_mode_id(const char *name) {
     if (!name) return -1;
-    static const char *names[] = {"reflect", "symmetric", "periodic", "zero", "constant", "smooth", "antisymmetric", "antireflect"};
-    for (int i = 0; i < 8; i++)
+    static const char *names[] = {"reflect", "symmetric", "periodic", "zero", "constant", "smooth", "antisymmetric", "antireflect",
+                                  "periodization"};
+    for (int i = 0; i < 9; i++)
         if (!strcmp(names[i], name)) return i;
     return -1;
 }
 
+extern "C" int spiht_geometry_mode(int64_t H, int64_t W, int wavelet, int mode, int level, int *level_used, int64_t *ll_h,
+                                   int64_t *ll_w, int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W);
 extern "C" int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h,
                               int64_t *ll_w, int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W) {
-    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS) return SPIHT_ERR_ARG;
+    return spiht_geometry_mode(H, W, wavelet, SPIHT_MODE_REFLECT, level, level_used, ll_h, ll_w, enc_h, enc_w, rec_H, rec_W);
+}
+extern "C" int spiht_geometry_mode(int64_t H, int64_t W, int wavelet, int mode, int level, int *level_used, int64_t *ll_h,
+                                   int64_t *ll_w, int64_t *enc_h, int64_t *enc_w, int64_t *rec_H, int64_t *rec_W) {
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > SPIHT_MODE_PERIODIZATION) return SPIHT_ERR_ARG;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     if (level_used) *level_used = ig.L;
     if (ll_h) *ll_h = ig.ll_h;
     if (ll_w) *ll_w = ig.ll_w;
@@ -1161,6 +1174,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
 // level-1 approximation then comes out of the packed array too; a filter whose halo exceeds a tile)
 static bool l1flags_geometry(const ImgGeom &ig, int F, L1Flags *fl) {
     memset(fl, 0, sizeof(*fl));
+    if (ig.per) return false;  // (periodization runs the plain two-pass inverse: no tiles)
     if (ig.L < 2 || F / 2 - 1 > IW_TH / 2 || F / 2 - 1 > IW_TW / 2) return false;
     fl->off_h = (int32_t)ig.offh[1]; fl->off_w = (int32_t)ig.offw[1];
     fl->band_h = (int32_t)ig.hs[1]; fl->band_w = (int32_t)ig.ws[1];
@@ -1188,14 +1202,15 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
     }
     // intermediate approximations ping-pong between a0/a1; sizes 2*band-F+2
     size_t maxa = 0;
-    for (int l = l_hi; l > l_lo; l--) maxa = std::max(maxa, (size_t)(2 * ig.hs[l] - F + 2) * (size_t)(2 * ig.ws[l] - F + 2));
+    const int Fg = ig.per ? 2 : F;  // (the length rule's filter length: periodization gives back 2 n samples)
+    for (int l = l_hi; l > l_lo; l--) maxa = std::max(maxa, (size_t)(2 * ig.hs[l] - Fg + 2) * (size_t)(2 * ig.ws[l] - Fg + 2));
     if (maxa) {
         CHK(ensure(ctx, ctx->a0, maxa * planes * 8));
         CHK(ensure(ctx, ctx->a1, maxa * planes * 8));
     }
     const double *a_in = d_a_in;
     int64_t ah = ig.ll_h, aw = ig.ll_w;
-    if (l_hi < ig.L) { ah = 2 * ig.hs[l_hi + 1] - F + 2; aw = 2 * ig.ws[l_hi + 1] - F + 2; }
+    if (l_hi < ig.L) { ah = 2 * ig.hs[l_hi + 1] - Fg + 2; aw = 2 * ig.ws[l_hi + 1] - Fg + 2; }
     for (int l = l_hi; l >= l_lo; l--) {
         IdwtKArgs a;
         memset(&a, 0, sizeof(a));
@@ -1206,6 +1221,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         a.a_h = (int32_t)ah; a.a_w = (int32_t)aw;
         // waverec2 trim rule: the running approximation may be exactly one longer than the band
         if (!((ah == ig.hs[l] || ah == ig.hs[l] + 1) && (aw == ig.ws[l] || aw == ig.ws[l] + 1))) return SPIHT_ERR_ARG;
+        if (ig.per) { a.out_h = (int32_t)(2 * ig.hs[l]); a.out_w = (int32_t)(2 * ig.ws[l]); }
         a.off_h = (int32_t)ig.offh[l]; a.off_w = (int32_t)ig.offw[l];
         a.enc_h = (int32_t)ig.enc_h; a.enc_w = (int32_t)ig.enc_w;
         a.first = (l == ig.L) ? 1 : 0;
@@ -1218,7 +1234,28 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         if (l == 1 && !a.first && !a.color) a.flags = d_flags;
         memcpy(a.lo, wv.rec_lo, sizeof(double) * F);
         memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
-        {
+        if (ig.per) {
+            // periodization: two plain passes through an intermediate (dwt.hip: k_idwt_axis_per), a few planes at a time; the
+            // colour model of the picture as a pass of its own behind level 1
+            StageTimer t(ctx, l == 1 ? ST_IDWT_L1 : ST_IDWT_REST);
+            a.color = 0;
+            const size_t per_plane = (size_t)2 * a.band_h * a.out_w * 8;
+            int pc = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_plane);
+            pc = std::max(c, pc / c * c);
+            CHK(ensure(ctx, ctx->exttmp, per_plane * (size_t)std::min(pc, planes)));
+            for (int p0 = 0; p0 < planes; p0 += pc) {
+                const int np = std::min(pc, planes - p0);
+                IdwtKArgs b = a;
+                if (b.a_in) b.a_in = a.a_in + (size_t)p0 * a.a_h * a.a_w;
+                b.rec = a.rec + (size_t)p0 * a.enc_h * a.enc_w;
+                b.out = a.out + (size_t)p0 * a.out_h * a.out_w;
+                double *t_lo = (double *)ctx->exttmp.p, *t_hi = t_lo + (size_t)np * a.band_h * a.out_w;
+                LAUNCHCHK(spiht_launch_idwt_level_per(&b, np, t_lo, t_hi, ctx->stream));
+            }
+            if (color && l == 1)
+                LAUNCHCHK(spiht_launch_color3(a.out, a.out, planes / 3, (size_t)a.out_h * a.out_w, ctx->col_inv.A, ctx->col_inv.M,
+                                              ctx->col_inv.p, ctx->stream));
+        } else {
             StageTimer t(ctx, l == 1 ? ST_IDWT_L1 : ST_IDWT_REST);
             LAUNCHCHK(spiht_launch_idwt_level(&a, planes, ctx->stream, ctx->tilectr.dev ? &ctx->tilectr : nullptr));
         }
@@ -1230,7 +1267,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
 }
 
 static int check_img_args(int wavelet, int mode, int64_t B, int64_t c, int64_t H, int64_t W) {
-    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > SPIHT_MODE_ANTIREFLECT) return SPIHT_ERR_ARG;
+    if (wavelet < 0 || wavelet >= SPIHT_NWAVELETS || mode < 0 || mode > SPIHT_MODE_PERIODIZATION) return SPIHT_ERR_ARG;
     if (B < 0 || c < 1 || H < 1 || W < 1) return SPIHT_ERR_ARG;
     if (H > (1 << 24) || W > (1 << 24)) return SPIHT_ERR_TOO_LARGE;
     return SPIHT_OK;
@@ -1244,7 +1281,7 @@ static int dwt_quant_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int64_
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
@@ -1275,7 +1312,7 @@ static int dequant_idwt_batch(spiht_ctx *ctx, const int32_t *d_rec, const uint32
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const double *d_mults;
@@ -1312,7 +1349,8 @@ static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
+    if (ig.per) return SPIHT_ERR_ARG;  // (the two-part inverse is a schedule experiment of the tiled kernels)
     const bool coarse = d_img_out == nullptr;
     if (coarse && ig.L < 2) return SPIHT_OK;
     if (!coarse && ig.L >= 2 && !d_approx) return SPIHT_ERR_ARG;
@@ -1369,7 +1407,7 @@ static int encode_image_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1420,7 +1458,7 @@ extern "C" int spiht_decode_image_batch_f64(spiht_ctx *ctx, const uint8_t *d_dat
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1482,7 +1520,7 @@ static int encode_image_host(spiht_ctx *ctx, const void *img, bool f32, int64_t 
     if (!ctx || !img || !out_nbits || !max_n || (!out && out_cap)) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, 1, c, H, W));
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1540,7 +1578,7 @@ extern "C" int spiht_decode_image_host_f64(spiht_ctx *ctx, const uint8_t *data, 
     if (!ctx || !img_out || (!data && nbytes)) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, 1, c, H, W));
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     if (n > 30) return SPIHT_ERR_MAGNITUDE;
     if (nbytes * 8 >= 0xFFFFFF00ull) return SPIHT_ERR_TOO_LARGE;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1578,7 +1616,7 @@ extern "C" int spiht_dequant_idwt_host_f64(spiht_ctx *ctx, const int32_t *rec, i
     if (!ctx || !rec || !img_out) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, 1, c, H, W));
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     const size_t rec_bytes = (size_t)c * ig.enc_h * ig.enc_w * 4, out_bytes = (size_t)c * ig.rec_H * ig.rec_W * 8;
@@ -1610,7 +1648,7 @@ extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, 
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -1687,12 +1725,12 @@ extern "C" int spiht_decode_lists_batch_i32(spiht_ctx *ctx, const uint8_t *d_dat
 // for spiht_dequant_idwt_flags_batch_f64.  d_flags == NULL or a geometry without flags: as spiht_decode_lists_batch_i32.
 extern "C" int spiht_decode_lists_flags_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_stride,
                                                   const uint64_t *d_nbytes, const uint8_t *d_max_n, int64_t B, int64_t c,
-                                                  int64_t H, int64_t W, int wavelet, int level, int32_t *d_out_zeroed,
+                                                  int64_t H, int64_t W, int wavelet, int mode, int level, int32_t *d_out_zeroed,
                                                   uint32_t *d_flags) {
     if (!ctx || !d_data || !d_nbytes || !d_max_n || !d_out_zeroed || B < 0) return SPIHT_ERR_ARG;
-    CHK(check_img_args(wavelet, 0, B, c, H, W));
+    CHK(check_img_args(wavelet, mode, B, c, H, W));
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     Geom g;
     CHK(make_geom(c, ig.enc_h, ig.enc_w, ig.ll_h, ig.ll_w, &g));
     L1Flags fl;
@@ -1755,10 +1793,11 @@ extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t va
 
 // Size, in 32-bit words per image, of the occupancy words the decoder leaves for the inverse transform's level 1
 // (common.h: L1Flags): 0 when they do not apply to this geometry (fewer than two levels).
-extern "C" int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int level, uint64_t *words_per_image) {
-    if (!words_per_image || wavelet < 0 || wavelet >= SPIHT_NWAVELETS || c < 1) return SPIHT_ERR_ARG;
+extern "C" int spiht_l1_flags_words(int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level, uint64_t *words_per_image) {
+    if (!words_per_image || wavelet < 0 || wavelet >= SPIHT_NWAVELETS || c < 1 || mode < 0 || mode > SPIHT_MODE_PERIODIZATION)
+        return SPIHT_ERR_ARG;
     ImgGeom ig;
-    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig));
+    CHK(img_geometry(H, W, SPIHT_WAVELETS[wavelet].F, level, &ig, mode));
     L1Flags fl;
     *words_per_image = l1flags_geometry(ig, SPIHT_WAVELETS[wavelet].F, &fl) ? (uint64_t)c * fl.gy * fl.gx : 0;
     return SPIHT_OK;

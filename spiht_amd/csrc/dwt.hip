@@ -112,6 +112,11 @@ __device__ __forceinline__ int32_t quant(double v, double m, double q, bool has_
     return (int32_t)v;
 }
 __device__ __forceinline__ uint32_t iabs_u(int32_t x) { return (uint32_t)(x < 0 ? -x : x); }
+__device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
+    double v = (double)r;
+    if (has_m) v = v / m;
+    return v / q;
+}
 
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes).  LOM / HIM: bit j set = tap j of dec_lo / dec_hi is non-zero;
 // a zero tap contributes exactly nothing (0*x added to the running sum), so skipping it changes no bit and
@@ -249,6 +254,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     __shared__ double s_lo[2][PS];
     __shared__ double s_hi[2][PS];
     __shared__ int s_row[NR];
+#ifdef DWT_PRIO  // experiment: wave priority of the streaming kernels over whatever shares the CU with them
+    __builtin_amdgcn_s_setprio(DWT_PRIO);
+#endif
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
     dwt_tile<F, LOM, HIM, PS, NR, EMIT>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
@@ -823,6 +831,12 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
 // downsampling_convolution: taps ascending, except that on the right overhang of an input at least as long as the filter
 // the taps that read the extension come first, nearest first -- smooth, like constant, keeps ascending order there too.
 __device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, int i, int mode) {
+    if (mode == 8) {  // periodization: the signal, made even by repeating its last sample, continued periodically
+        const int Np = N + (N & 1);
+        int m = i % Np;
+        if (m < 0) m += Np;
+        return x[(size_t)(m < N ? m : N - 1) * sx];
+    }
     if (i >= 0 && i < N) return x[(size_t)i * sx];
     if (mode == 5) {  // smooth: the straight line through the two samples at the edge
         if (N < 2) return x[0];
@@ -859,6 +873,7 @@ __device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, i
 // stride sx, line stride sl; outputs: lo / hi [plane][L][n_lines] laid out with the same strides roles (so, sol)
 struct DwtAxisArgs {
     int32_t F, mode, N, L, n_lines, planes;
+    int32_t i0, pad;             // output o reads the window that ends at sample 2 o + i0: 1, or F / 2 under periodization
     size_t sx, sl, plane_in;     // input: element stride along the axis, stride between lines, plane stride
     size_t so, sol, plane_out;   // output alike
     const double *in;
@@ -876,7 +891,7 @@ __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
     if (a.so == 1) { line = (int)(r / a.L); o = (int)(r - (size_t)line * a.L); }
     else { o = (int)(r / a.n_lines); line = (int)(r - (size_t)o * a.n_lines); }
     const double *x = a.in + (size_t)plane * a.plane_in + (size_t)line * a.sl;
-    const int i = 2 * o + 1;
+    const int i = 2 * o + a.i0;
     const int jb = (i >= a.N && a.mode != 5) ? i - a.N : -1;
     double sa = 0.0, sd = 0.0;
     for (int s2 = 0; s2 < a.F; s2++) {
@@ -931,6 +946,7 @@ extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double 
     DwtAxisArgs x;
     memset(&x, 0, sizeof(x));
     x.F = a->F; x.mode = a->mode; x.planes = planes;
+    x.i0 = a->mode == 8 ? a->F / 2 : 1;
     for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; }
     // axis -2: lines = columns
     x.N = a->in_h; x.L = a->out_h; x.n_lines = a->in_w;
@@ -955,6 +971,92 @@ extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double 
     p.aa = b_aa; p.ad = b_ad; p.da = b_da; p.dd = b_dd;
     p.ll_out = a->ll_out; p.coeffs = a->coeffs; p.mults = a->mults; p.maxabs = a->maxabs; p.q = a->q;
     hipLaunchKernelGGL(k_dwt_pack_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    return (int)hipGetLastError();
+}
+
+// ---- inverse level under periodization (pywt upsampling_convolution_valid_sf_periodization) ---------------------------------
+// 2 L samples back from L + L coefficients: x[n] = sum_k rec[n - 2k + F/2 - 1] c[k mod L], i.e. with p = (n + F/2 - 1) & 1 and
+// i = (n + F/2 - 1 - p) / 2 the terms j = 0 .. F/2-1: tap 2j + p against c[(i - j) mod L]; pywt adds every product straight
+// into the output sample, the approximation's first, then the detail's; where the window hangs over the right end (i >= L)
+// the terms beyond it come first, nearest first -- and sample 0 of a filter with an even number of tap pairs is summed
+// like the odd half of the last window (jb = F/4 - 1).  One thread per output sample, two passes (axis -1, then axis -2)
+// through an intermediate: the plain form of a mode nobody's headline runs on.
+struct IdwtPerArgs {
+    int32_t F, L, n_lines, planes;     // L coefficients per line, n_lines lines
+    size_t si, so;                     // element stride along the axis: inputs, output
+    size_t sla, sld, slo;              // stride between lines: approximation input, detail input, output
+    size_t plane_a, plane_d, plane_out;
+    const double *ca, *cd;             // float inputs ...
+    const int32_t *qa, *qd;            // ... or quantised ones (dequantised on the fly, (v / m) / q as the wrapper does)
+    int32_t a_is_q, d_is_q, c, has_m;
+    const double *mults;
+    double q;
+    double *out;
+    double flo[SPIHT_MAX_TAPS], fhi[SPIHT_MAX_TAPS];
+};
+__global__ __launch_bounds__(256) void k_idwt_axis_per(IdwtPerArgs a) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_plane = (size_t)2 * a.L * a.n_lines;
+    if (t >= per_plane * (size_t)a.planes) return;
+    const int plane = (int)(t / per_plane);
+    const size_t r = t - (size_t)plane * per_plane;
+    int n, line;  // consecutive threads along the contiguous direction of the output
+    if (a.so == 1) { line = (int)(r / (2 * (size_t)a.L)); n = (int)(r - (size_t)line * 2 * a.L); }
+    else { n = (int)(r / a.n_lines); line = (int)(r - (size_t)n * a.n_lines); }
+    const int HF = a.F / 2, s0 = HF - 1;
+    const int p = (n + s0) & 1, i = (n + s0 - p) / 2;
+    int jb = i >= a.L ? i - a.L : -1;
+    if (n == 0 && (HF & 1) == 0) jb = a.F / 4 - 1;
+    const bool has_m = a.has_m != 0;
+    const double mk = has_m ? a.mults[plane % a.c] : 1.0;
+    const size_t ba = (size_t)plane * a.plane_a + (size_t)line * a.sla, bd = (size_t)plane * a.plane_d + (size_t)line * a.sld;
+    double acc = 0.0;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const double *f = pass ? a.fhi : a.flo;
+        for (int s2 = 0; s2 < HF; s2++) {
+            const int j = s2 <= jb ? jb - s2 : s2;
+            int k = (i - j) % a.L;
+            if (k < 0) k += a.L;
+            double v;
+            if (pass == 0) v = a.a_is_q ? dequant(a.qa[ba + (size_t)k * a.si], mk, a.q, has_m) : a.ca[ba + (size_t)k * a.si];
+            else v = a.d_is_q ? dequant(a.qd[bd + (size_t)k * a.si], mk, a.q, has_m) : a.cd[bd + (size_t)k * a.si];
+            acc += f[2 * j + p] * v;
+        }
+    }
+    a.out[(size_t)plane * a.plane_out + (size_t)line * a.slo + (size_t)n * a.so] = acc;
+}
+// t_lo, t_hi: planes * band_h * out_w doubles each (out_w = 2 band_w, out_h = 2 band_h)
+extern "C" int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, hipStream_t st) {
+    IdwtPerArgs x;
+    memset(&x, 0, sizeof(x));
+    x.F = a->F; x.planes = planes; x.c = a->c; x.has_m = a->mults != nullptr; x.mults = a->mults; x.q = a->q;
+    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; }
+    const size_t enc_plane = (size_t)a->enc_h * a->enc_w;
+    // axis -1 (PyWavelets' idwtn takes the last axis first): band_h lines of band_w coefficients -> out_w samples
+    x.L = a->band_w; x.n_lines = a->band_h;
+    x.si = 1; x.so = 1; x.slo = (size_t)a->out_w; x.plane_out = (size_t)a->band_h * a->out_w;
+    const size_t n1 = (size_t)planes * 2 * x.L * x.n_lines;
+    // (aa, ad) -> low rows: the approximation comes out of the packed array (coarsest level) or from the level before, whose
+    // array may be one sample longer than the band in either direction (waverec2 drops it)
+    if (a->first) { x.a_is_q = 1; x.qa = a->rec; x.plane_a = enc_plane; x.sla = (size_t)a->enc_w; }
+    else { x.a_is_q = 0; x.ca = a->a_in; x.plane_a = (size_t)a->a_h * a->a_w; x.sla = (size_t)a->a_w; }
+    x.d_is_q = 1; x.qd = a->rec + a->off_w; x.plane_d = enc_plane; x.sld = (size_t)a->enc_w;
+    x.out = t_lo;
+    hipLaunchKernelGGL(k_idwt_axis_per, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, x);
+    // (da, dd) -> high rows
+    x.a_is_q = 1; x.qa = a->rec + (size_t)a->off_h * a->enc_w; x.plane_a = enc_plane; x.sla = (size_t)a->enc_w;
+    x.qd = a->rec + (size_t)a->off_h * a->enc_w + a->off_w;
+    x.out = t_hi;
+    hipLaunchKernelGGL(k_idwt_axis_per, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, x);
+    // axis -2: out_w lines (columns) of band_h coefficients -> out_h samples
+    x.L = a->band_h; x.n_lines = a->out_w;
+    x.si = (size_t)a->out_w; x.sla = 1; x.sld = 1; x.plane_a = x.plane_d = (size_t)a->band_h * a->out_w;
+    x.so = (size_t)a->out_w; x.slo = 1; x.plane_out = (size_t)a->out_h * a->out_w;
+    x.a_is_q = 0; x.d_is_q = 0; x.ca = t_lo; x.cd = t_hi;
+    x.out = a->out;
+    const size_t n2 = (size_t)planes * 2 * x.L * x.n_lines;
+    hipLaunchKernelGGL(k_idwt_axis_per, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, x);
     return (int)hipGetLastError();
 }
 
@@ -1006,11 +1108,6 @@ __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double
 // 4.02 ms, 20: 4.05, 24: 4.03, 32: 4.19, 12: 4.22, 40: 4.67, 8: 4.74; persistent kernel beside the list decoder (the
 // pipelined schedule): 16 rows 7.3 ms, 20: 7.0, 24: 6.5-6.7, 28: 8.1, 32: 7.6
 
-__device__ __forceinline__ double dequant(int32_t r, double m, double q, bool has_m) {
-    double v = (double)r;
-    if (has_m) v = v / m;
-    return v / q;
-}
 
 // grid: (ceil(out_w/TW), ceil(out_h/TH), planes).  LOM / HIM: non-zero taps of rec_lo / rec_hi (a product with a
 // zero tap adds exactly nothing to `ca*lo + cd*hi`, so it is skipped).
@@ -1022,6 +1119,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
     constexpr int KW = IW_TW / 2 + HF - 1;   // band cols staged
     constexpr int KHH = IW_TH / 4 + HF - 1;  // band rows one half-tile walks
     __shared__ double s_b[4][KH][KW + 1];    // aa, ad, da, dd (dequantised)
+#ifdef IDWT_PRIO
+    __builtin_amdgcn_s_setprio(IDWT_PRIO);
+#endif
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IW_TH - 1) / IW_TH, a.planes, tbx, tby, tbz);
     const int plane = (int)tbz;
@@ -1165,6 +1265,9 @@ template <int F, uint32_t LOM, uint32_t HIM, bool FIRST, bool FLAGS = false>  //
 __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr,
                                                                       TileBase cb) {
     static_assert(!(FIRST && FLAGS), "the flags are those of level 1 of a transform with two levels or more");
+#ifdef IDWT_PRIO
+    __builtin_amdgcn_s_setprio(IDWT_PRIO);
+#endif
     constexpr int HF = F / 2;
     constexpr int KH = IW_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IW_TH / 4 + HF - 1;
     constexpr int NE = (KH * KW + DW_BLOCK - 1) / DW_BLOCK;  // staged elements per thread

@@ -83,9 +83,9 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
     p->wavelet = wavelet; p->mode = mode; p->level = level; p->q = q_scale;
     if (channel_mults) p->mults.assign(channel_mults, channel_mults + c);
     p->max_bits = max_bits == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits;
-    int st = spiht_geometry(H, W, wavelet, level, nullptr, &p->ll_h, &p->ll_w, &p->enc_h, &p->enc_w, nullptr, nullptr);
+    int st = spiht_geometry_mode(H, W, wavelet, mode, level, nullptr, &p->ll_h, &p->ll_w, &p->enc_h, &p->enc_w, nullptr, nullptr);
     if (st == SPIHT_OK) st = spiht_encode_bound(c, p->enc_h, p->enc_w, p->ll_h, p->ll_w, 0x3FFFFFFFu, p->max_bits, &p->slot_stride);
-    if (st == SPIHT_OK) st = spiht_l1_flags_words(c, H, W, wavelet, level, &p->flag_words);
+    if (st == SPIHT_OK) st = spiht_l1_flags_words(c, H, W, wavelet, mode, level, &p->flag_words);
     if (st != SPIHT_OK) { pipeline_free(p); return st; }
     if (p->slot_stride < 4) p->slot_stride = 4;
     if (!p->Hc && (st = spiht_ctx_create(device, &p->Hc)) != SPIHT_OK) { pipeline_free(p); return st; }
@@ -135,7 +135,7 @@ extern "C" void spiht_pipeline_destroy(spiht_pipeline *p) { pipeline_free(p); }
 extern "C" int spiht_pipeline_info(spiht_pipeline *p, uint64_t *slot_stride, int64_t *rec_H, int64_t *rec_W) {
     if (!p) return SPIHT_ERR_ARG;
     if (slot_stride) *slot_stride = p->slot_stride;
-    return spiht_geometry(p->H, p->W, p->wavelet, p->level, nullptr, nullptr, nullptr, nullptr, nullptr, rec_H, rec_W);
+    return spiht_geometry_mode(p->H, p->W, p->wavelet, p->mode, p->level, nullptr, nullptr, nullptr, nullptr, nullptr, rec_H, rec_W);
 }
 
 extern "C" int spiht_pipeline_contexts(spiht_pipeline *p, spiht_ctx **h, spiht_ctx **l0, spiht_ctx **l1) {
@@ -191,7 +191,7 @@ extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_i
     }
     CHK(spiht_nbits_to_nbytes(L, x_nbits, p->B, p->nbytes[s]));
     CHK(spiht_decode_lists_flags_batch_i32(L, x_out, p->slot_stride, p->nbytes[s], x_maxn, p->B, p->c, p->H, p->W, p->wavelet,
-                                           p->level, p->rec[s], p->flags[s]));
+                                           p->mode, p->level, p->rec[s], p->flags[s]));
     CHK(spiht_event_record(p->ev_d[s], L));
     p->used[s] = true;
     // H: back half of the previous batch's decoder (beside this batch's decoder)

@@ -73,22 +73,19 @@ def _wavelet_mode_ids(spiht_settings):
     mid = L.spiht_mode_id(str(spiht_settings.mode).encode())
     if mid < 0:
         # pywt.Modes.from_object raises ValueError("Unknown mode name '...'.") (reached from spiht_wrapper.py:163)
-        if str(spiht_settings.mode) == "periodization":
-            raise ValueError("mode 'periodization' (PyWavelets' other length rule, ceil(n / 2) coefficients per level) is not "
-                             "supported; supported: reflect, symmetric, periodic, zero, constant, smooth, antisymmetric, "
-                             "antireflect")
         raise ValueError("Unknown mode name '%s'." % spiht_settings.mode)
     return wid, mid
 
 
-def _geometry(h, w, wid, level):
+def _geometry(h, w, wid, level, mid=0):
+    """sizes of the packed coefficient array; mid: the extension mode's id (periodization has its own length rule)"""
     L = _lib.lib()
     lv = C.c_int()
     v = [C.c_int64() for _ in range(6)]
     if level is not None and level < 0:
         raise ValueError("Level value of %d is too low . Minimum level is 0." % level)
-    _lib.check(L.spiht_geometry(int(h), int(w), wid, -1 if level is None else int(level), C.byref(lv),
-                                *[C.byref(t) for t in v]))
+    _lib.check(L.spiht_geometry_mode(int(h), int(w), wid, int(mid), -1 if level is None else int(level), C.byref(lv),
+                                     *[C.byref(t) for t in v]))
     return dict(level=lv.value, ll_h=v[0].value, ll_w=v[1].value, enc_h=v[2].value, enc_w=v[3].value,
                 rec_h=v[4].value, rec_w=v[5].value)
 
@@ -102,9 +99,9 @@ def _filter_len(wavelet):
 def get_slices_and_h_w(h: int, w: int, spiht_settings: SpihtSettings, level: Optional[int]):
     """wrapper:92-139: the pywt.coeffs_to_array slices of a (1,h,w) wavedec2, the height and the width of the
     packed coefficient array.  Closed form len' = (len + F - 1)//2 instead of pywt.wavedecn_shapes."""
-    wid, _ = _wavelet_mode_ids(spiht_settings)
-    g = _geometry(h, w, wid, level)
-    hs, ws = _band_sizes(h, w, spiht_settings.wavelet, g["level"])
+    wid, mid = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(h, w, wid, level, mid)
+    hs, ws = _band_sizes(h, w, spiht_settings.wavelet, g["level"], spiht_settings.mode)
     start_h, start_w = hs[-1], ws[-1]
     slices: List[Any] = [(slice(None), slice(start_h), slice(start_w))]
     for lv in range(g["level"], 0, -1):
@@ -147,7 +144,7 @@ def encode_image(image: np.ndarray, spiht_settings: SpihtSettings = SpihtSetting
             image = image.astype(np.float64)  # colour-science computes in float64; so does the transform that follows
 
     wid, mid = _wavelet_mode_ids(spiht_settings)
-    g = _geometry(h, w, wid, level)
+    g = _geometry(h, w, wid, level, mid)
     mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
 
     if max_bits == None:  # noqa: E711  (as the reference)
@@ -192,7 +189,7 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
         raise ValueError(encoding_result._encoding_version)
     h, w, c, level = encoding_result.h, encoding_result.w, encoding_result.c, encoding_result.level
     wid, mid = _wavelet_mode_ids(spiht_settings)
-    g = _geometry(h, w, wid, level)
+    g = _geometry(h, w, wid, level, mid)
     buf = spiht_rs._as_u8_vec(encoding_result.encoded_bytes)
     n = spiht_rs._as_usize(encoding_result.max_n, "n")
     if n > 255:
@@ -210,10 +207,10 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
     return out
 
 
-def _band_sizes(h, w, wavelet, levels):
-    """band heights / widths per level, [0] = the image: len' = (len + F - 1) // 2 (pywt.dwt_coeff_len, every mode but
-    periodization)"""
-    F = _filter_len(wavelet)
+def _band_sizes(h, w, wavelet, levels, mode="reflect"):
+    """band heights / widths per level, [0] = the image: len' = (len + F - 1) // 2 (pywt.dwt_coeff_len), under periodization
+    ceil(len / 2) -- the same rule with a two-tap filter"""
+    F = 2 if str(mode) == "periodization" else _filter_len(wavelet)
     hs, ws = [int(h)], [int(w)]
     for _ in range(levels):
         hs.append((hs[-1] + F - 1) // 2)
@@ -226,8 +223,8 @@ def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSetti
     if encoding_result._encoding_version != ENCODER_DECODER_VERSION:
         raise ValueError(encoding_result._encoding_version)
     er = encoding_result
-    wid, _ = _wavelet_mode_ids(spiht_settings)
-    g = _geometry(er.h, er.w, wid, er.level)
+    wid, mid = _wavelet_mode_ids(spiht_settings)
+    g = _geometry(er.h, er.w, wid, er.level, mid)
     slices, enc_h, enc_w = get_slices_and_h_w(er.h, er.w, spiht_settings, er.level)  # (returned to the caller, as the reference does)
     spiht_metadata = None
     if not return_metadata:
@@ -237,7 +234,7 @@ def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSetti
         # level (coarsest first) the filters in the order the reference hands them over, 'da', 'ad', 'dd' (wrapper:240).
         # (The reference reads them off pywt's slice objects, whose `start` is None on the approximation side -- which
         # PyO3 refuses, wrapper:242-245; here they come from the band sizes, so every start is a number.)
-        hs, ws = _band_sizes(er.h, er.w, spiht_settings.wavelet, g["level"])
+        hs, ws = _band_sizes(er.h, er.w, spiht_settings.wavelet, g["level"], spiht_settings.mode)
         top_box = [(0, g["ll_h"]), (0, g["ll_w"])]
         level_boxes = []
         row0, col0 = g["ll_h"], g["ll_w"]  # where the detail blocks of the level start
@@ -255,7 +252,7 @@ def decode_rec_array(encoding_result: EncodingResult, spiht_settings: SpihtSetti
 def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settings: SpihtSettings, slices=None):
     """wrapper:259-281: (rec / channel_mults) / q -> inverse DWT -> colour back.  Runs on the GPU."""
     wid, mid = _wavelet_mode_ids(spiht_settings)
-    g = _geometry(h, w, wid, level)
+    g = _geometry(h, w, wid, level, mid)
     rec = np.ascontiguousarray(rec_arr, dtype=np.int32)
     if rec.ndim != 3 or rec.shape[1] != g["enc_h"] or rec.shape[2] != g["enc_w"]:
         raise ValueError("rec_arr shape %s does not match the coefficient array (c,%d,%d)"

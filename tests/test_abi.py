@@ -66,7 +66,7 @@ def test_geometry_and_bound_without_gpu():
     assert L.spiht_encode_bound(1, 8, 8, 1, 2, 5, 0, C.byref(b)) == _lib.ERR_LL
     assert L.spiht_encode_bound(1, 6, 8, 4, 2, 5, 0, C.byref(b)) == _lib.ERR_SHAPE
     assert L.spiht_wavelet_id(b"bior2.2") >= 0 and L.spiht_wavelet_id(b"nope") < 0
-    assert L.spiht_mode_id(b"reflect") == 0 and L.spiht_mode_id(b"smooth") == 5 and L.spiht_mode_id(b"periodization") < 0
+    assert L.spiht_mode_id(b"reflect") == 0 and L.spiht_mode_id(b"smooth") == 5 and L.spiht_mode_id(b"periodization") == 8 and L.spiht_mode_id(b"nope") < 0
 
 
 def test_geometry_matches_golden_pywt_shapes():

@@ -20,7 +20,7 @@ def _gpu_dwt(img, wavelet, mode, level, q, mults):
     wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
     v = [C.c_int64() for _ in range(6)]
     lv = C.c_int()
-    _lib.check(L.spiht_geometry(H, W, wid, -1 if level is None else level, C.byref(lv), *[C.byref(t) for t in v]))
+    _lib.check(L.spiht_geometry_mode(H, W, wid, mid, -1 if level is None else level, C.byref(lv), *[C.byref(t) for t in v]))
     eh, ew = v[2].value, v[3].value
     out = np.empty((B, c, eh, ew), np.int32)
     d_in, d_out = ctx.alloc(img.nbytes), ctx.alloc(out.nbytes)
@@ -46,7 +46,7 @@ def _gpu_idwt(rec, H, W, wavelet, mode, level, q, mults):
     wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
     v = [C.c_int64() for _ in range(6)]
     lv = C.c_int()
-    _lib.check(L.spiht_geometry(H, W, wid, -1 if level is None else level, C.byref(lv), *[C.byref(t) for t in v]))
+    _lib.check(L.spiht_geometry_mode(H, W, wid, mid, -1 if level is None else level, C.byref(lv), *[C.byref(t) for t in v]))
     out = np.empty((B, c, v[4].value, v[5].value), np.float64)
     d_in, d_out = ctx.alloc(rec.nbytes), ctx.alloc(out.nbytes)
     m = None if mults is None else np.ascontiguousarray(mults, np.float64)
@@ -350,12 +350,12 @@ def test_level1_tile_occupancy_words(oracle, case):
     d_rec = DeviceArray(ctx, (B, n), np.int32)
     d_rec.zero()
     nw = C.c_uint64()
-    _lib.check(L.spiht_l1_flags_words(c, H, W, cd.wid, cd._lv, C.byref(nw)))
+    _lib.check(L.spiht_l1_flags_words(c, H, W, cd.wid, cd.mid, cd._lv, C.byref(nw)))
     assert (nw.value > 0) == (g["level"] >= 2)
     d_fl = DeviceArray(ctx, (B, max(nw.value, 1)), np.uint32)
     ctx.memset(d_fl.ptr, 0xEE, d_fl.nbytes)  # (the call zero-fills them itself)
     _lib.check(L.spiht_decode_lists_flags_batch_i32(ctx.handle, vp(d_data.ptr), stride, vp(d_nb.ptr), vp(d_mn.ptr), B, c, H, W,
-                                                    cd.wid, cd._lv, vp(d_rec.ptr), vp(d_fl.ptr if nw.value else None)))
+                                                    cd.wid, cd.mid, cd._lv, vp(d_rec.ptr), vp(d_fl.ptr if nw.value else None)))
     outs = []
     for fl in (d_fl.ptr if nw.value else None, None):
         d_img = DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64)
@@ -422,25 +422,22 @@ def test_every_wavelet_up_to_20_taps(oracle):
 
 
 def test_computed_extension_modes(oracle):
-    """smooth / antisymmetric / antireflect (the reference passes SpihtSettings.mode to PyWavelets as it is): the two-pass
-    forward level (dwt.hip: k_dwt_axis_ext) against PyWavelets 1.1.1 (tests/golden/modes_pywt.npz) and, on a batch of
+    """smooth / antisymmetric / antireflect / periodization (the reference passes SpihtSettings.mode to PyWavelets as it is):
+    the two-pass forward level (dwt.hip: k_dwt_axis_ext) and, for periodization -- another length rule, ceil(n / 2) -- the
+    two-pass inverse level (k_idwt_axis_per) against PyWavelets 1.1.1 (tests/golden/modes_pywt.npz) and, on a batch of
     pictures larger than a tile with channel scales and a colour model, against the oracle; the coder behind it included."""
     import spiht_amd
     from test_oracle import transform_cases
     n = 0
     for cs in transform_cases("modes_pywt.npz"):
-        if cs["mode"] == "periodization":
-            with pytest.raises(ValueError):
-                spiht_amd.encode_image(cs["img"], spiht_amd.SpihtSettings(wavelet=cs["wavelet"], mode=cs["mode"]), cs["level"])
-            continue
         got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
         bad = np.argwhere(got != cs["quant"])
         assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, len(bad), bad[:4])
         back = _gpu_idwt(cs["rec"][None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
         assert np.array_equal(back, cs["rec_img"])
         n += 1
-    assert n == 30
-    for mode in ("smooth", "antisymmetric", "antireflect"):
+    assert n == 40
+    for mode in ("smooth", "antisymmetric", "antireflect", "periodization"):
         imgs = np.stack([synth_image(90 + b, 3, 131, 203) for b in range(3)])
         got = _gpu_dwt(imgs, "bior4.4", mode, 3, 50.0, [1.0, 0.5, 2.0])
         for b in range(3):
@@ -451,7 +448,7 @@ def test_computed_extension_modes(oracle):
         ref_bytes, ref_n, _ = oracle.encode_image(imgs[0], "bior2.2", mode, 3, 50.0, None, 20000)
         assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n, mode
         dec = spiht_amd.decode_image(enc, s)
-        assert np.array_equal(dec, oracle.decode_image(ref_bytes, ref_n, 3, 131, 203, "bior2.2", 3, 50.0, None))
+        assert np.array_equal(dec, oracle.decode_image(ref_bytes, ref_n, 3, 131, 203, "bior2.2", 3, 50.0, None, mode=mode))
         # with a colour model: the change runs as a pass of its own in front of the two-pass level
         sc = spiht_amd.SpihtSettings(mode=mode, quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
         e2 = spiht_amd.encode_image(imgs[1], sc, 3, 20000)

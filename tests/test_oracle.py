@@ -398,20 +398,19 @@ def test_every_wavelet_up_to_20_taps_matches_pywt(oracle):
 
 def test_computed_extension_modes_match_pywt(oracle):
     """smooth, antisymmetric and antireflect -- PyWavelets' extension modes that compute the samples beyond the edge instead
-    of picking them -- against PyWavelets 1.1.1 (tests/golden/modes_pywt.npz): the float64 packed array in every bit, the
-    int32 array, the picture back (the inverse transform does not depend on the mode)."""
+    of picking them -- and periodization (another length rule, its own inverse) against PyWavelets 1.1.1
+    (tests/golden/modes_pywt.npz): the float64 packed array in every bit, the int32 array, the picture back."""
     n = 0
     for cs in transform_cases("modes_pywt.npz"):
-        if cs["mode"] == "periodization":
-            continue  # another length rule: not built (DESIGN.md 8)
         arr, _ = oracle.wavedec2_array(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
         assert arr.shape == cs["arr"].shape
         assert np.array_equal(arr.view(np.uint64), cs["arr"].view(np.uint64)), (cs["wavelet"], cs["mode"], cs["level"])
         assert np.array_equal(oracle.quantize(arr, cs["q"]), cs["quant"])
-        back = oracle.waverec2_array(oracle.dequantize(cs["rec"], cs["q"]), cs["H"], cs["W"], cs["wavelet"], cs["level"])
-        assert np.array_equal(back.view(np.uint64), cs["rec_img"].view(np.uint64))
+        back = oracle.waverec2_array(oracle.dequantize(cs["rec"], cs["q"]), cs["H"], cs["W"], cs["wavelet"], cs["level"], cs["mode"])
+        assert back.shape == cs["rec_img"].shape
+        assert np.array_equal(back.view(np.uint64), cs["rec_img"].view(np.uint64)), (cs["wavelet"], cs["mode"], cs["level"])
         n += 1
-    assert n == 30
+    assert n == 40
 
 
 def short_cases():

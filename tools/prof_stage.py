@@ -44,11 +44,11 @@ ctx.synchronize()
 d_fl = None
 if stage == "idwtf":
     nw = C.c_uint64()
-    _lib.check(L.spiht_l1_flags_words(C_IMG, H, W, codec.wid, LEVEL, C.byref(nw)))
+    _lib.check(L.spiht_l1_flags_words(C_IMG, H, W, codec.wid, codec.mid, LEVEL, C.byref(nw)))
     d_fl = DeviceArray(ctx, (B, nw.value), np.uint32)
     ctx.memset(d_rec.ptr, 0, d_rec.nbytes)
     _lib.check(L.spiht_decode_lists_flags_batch_i32(ctx.handle, vp(d_out.ptr), codec.slot_stride, vp(d_nbytes.ptr), vp(d_maxn.ptr), B,
-                                                    C_IMG, H, W, codec.wid, LEVEL, vp(d_rec.ptr), vp(d_fl.ptr)))
+                                                    C_IMG, H, W, codec.wid, codec.mid, LEVEL, vp(d_rec.ptr), vp(d_fl.ptr)))
     ctx.synchronize()
     print("occupied_tiles_fraction %.5f" % float(d_fl.download().mean()))
 for _ in range(iters):
