@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--l1-flags", type=int, default=1,
                     help="1 (default): the list decoder flags the occupied level-1 tiles and the inverse transform does not read the "
                          "detail bands of the others (include/spiht_hip.h: spiht_decode_lists_flags_batch_i32); 0: reads everything")
+    ap.add_argument("--coarse-first", type=int, default=0,
+                    help="experiment (--pipeline 2): the coarse inverse levels of step i-1 between the transform and the pyramid of "
+                         "step i, where the list-coding streams are idle")
     ap.add_argument("--d1-emit", type=int, default=0,
                     help="1: level 1 of the forward transform writes pyramid codes ahead of the pyramid pass (measured, not the "
                          "default: DESIGN.md 6)")
@@ -280,7 +283,8 @@ def main():
         codecs[k].decode_device(so + a * slot, d_nbytes.ptr + a * 8, sm + a, b - a, d_rec_img.ptr + a * rec_b)
 
     pipe = cpipe = None
-    if args.pipeline == 1 and K == 1 and pix == np.float64 and args.pair == "inverse" and args.decoder_waves == 8 and args.l1_flags:
+    if (args.pipeline == 1 and K == 1 and pix == np.float64 and args.pair == "inverse" and args.decoder_waves == 8 and args.l1_flags
+            and not args.coarse_first):
         # the same schedule queued by the library itself (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): what a
         # caller in any host language gets; three contexts of its own
         from spiht_amd.batch import Pipeline
@@ -293,7 +297,8 @@ def main():
         # list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).  The
         # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
         from spiht_amd.batch import OverlappedCodec
-        pipe = OverlappedCodec(codec, B, pair=args.pair, decoder_waves=args.decoder_waves, l1_flags=bool(args.l1_flags))
+        pipe = OverlappedCodec(codec, B, pair=args.pair, decoder_waves=args.decoder_waves, l1_flags=bool(args.l1_flags),
+                               coarse_first=bool(args.coarse_first))
         ctxs.extend(pipe.Ls)
 
     def step():
@@ -509,9 +514,17 @@ def main():
                                                        "%s images per launch)" % ot.get("images_per_launch", "?")
                 occ = ot.get("idwt_level1_with_occupancy_words", {}).get("%g bpp" % BPP)
                 if occ and other.get("idwt_level1") is not None and args.l1_flags:
-                    # what this run's inverse level 1 moves: the decoder's occupancy words are on, empty tiles' detail bands unread
-                    other["idwt_level1"]["with_occupancy_words"] = {k2: (round(v2) if k2.endswith("per_image") else v2)
-                                                                    for k2, v2 in occ.items()}
+                    # what this run's inverse level 1 moves: the decoder's occupancy words are on, empty tiles' detail bands
+                    # unread -- so its rate is quoted on the bytes it MOVES (PMC, this bit rate), not on the dense 81 MB / image
+                    o1 = other["idwt_level1"]
+                    o1["with_occupancy_words"] = {k2: (round(v2) if k2.endswith("per_image") else v2) for k2, v2 in occ.items()}
+                    moved = per_launch * occ["hbm_bytes_per_image"]
+                    o1["dense_bytes_frac"] = o1["frac"]
+                    o1["achieved_GBps"] = round(moved / (o1["ms_per_group"] * 1e-3) / 1e9, 1)
+                    o1["frac"] = round(o1["achieved_GBps"] / HBM_PEAK_GBS, 4)
+                    if "alone_ms" in o1:
+                        o1["dense_bytes_alone_frac"] = o1["alone_frac"]
+                        o1["alone_frac"] = round(moved / (o1["alone_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             except Exception:
                 pass
         # every HBM pass of a step counted once: the transform levels in both directions + the pyramid

@@ -273,6 +273,10 @@ int spiht_idwt_level1_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const doub
                                 int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
                                 const double *channel_mults, double *d_img_out);
 int spiht_idwt_approx_shape(int64_t H, int64_t W, int wavelet, int level, int64_t *a_h, int64_t *a_w);
+/* ... level 1 reading the decoder's occupancy words (spiht_decode_lists_flags_batch_i32; d_flags NULL: reads everything) */
+int spiht_idwt_level1_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const double *d_approx, const uint32_t *d_flags,
+                                      int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
+                                      const double *channel_mults, double *d_img_out);
 
 /* Colour model change on the device (the reference converts on the host through colour-science, color_models.py:6-13,
  * called from spiht_wrapper.py:158-160 and :278-279): B three-channel float64 images [B,3,npix]; per pixel

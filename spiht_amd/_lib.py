@@ -43,7 +43,7 @@ SYMBOLS = [
     "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
     "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_ctx_set_decoder_waves", "spiht_decode_budgets_i32", "spiht_decode_budgets_dev_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset", "spiht_dev_copy",
-    "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_approx_shape",
+    "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_level1_flags_batch_f64", "spiht_idwt_approx_shape",
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
     "spiht_dequant_idwt_host_f64",
     "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
@@ -128,6 +128,7 @@ def lib():
         L.spiht_dev_copy.argtypes = [vp, vp, vp, u64]
         L.spiht_idwt_coarse_batch_f64.argtypes = [vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
         L.spiht_idwt_level1_batch_f64.argtypes = [vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
+        L.spiht_idwt_level1_flags_batch_f64.argtypes = [vp, vp, vp, vp, i64, i64, i64, i64, i32, i32, i32, C.c_double, vp, vp]
         L.spiht_idwt_approx_shape.argtypes = [i64, i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
         L.spiht_encode_image_host_f64.argtypes = [vp, vp, i64, i64, i64, i32, i32, i32, C.c_double, vp, u64, vp, u64,
                                                   C.POINTER(u64), C.POINTER(u8)]

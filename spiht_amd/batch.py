@@ -226,7 +226,7 @@ class OverlappedCodec:
     gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
 
     def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=True,
-                 decoder_waves=8, l1_flags=True):
+                 decoder_waves=8, l1_flags=True, coarse_first=False):
         self.codec, self.B = codec, int(B)
         if pair not in ("forward", "inverse"):
             raise ValueError("pair must be 'forward' or 'inverse'")
@@ -252,7 +252,11 @@ class OverlappedCodec:
         ah, aw = C.c_int64(), C.c_int64()
         _lib.check(codec.L.spiht_idwt_approx_shape(codec.H, codec.W, codec.wid, codec._lv, C.byref(ah), C.byref(aw)))
         self.split = ah.value > 0 and split_inverse  # two levels or more: coarse levels on the list-coding stream
-        self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if self.split else [None, None]
+        # coarse_first: the coarse levels of I(i-1) between the transform and the pyramid of A(i) on H -- there the list-coding
+        # streams are idle (X(i-1) has ended, E(i) waits for the pyramid), so they run alone instead of beside the encoder
+        self.cf = ah.value > 0 and coarse_first and not self.split and pair == "inverse"
+        self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if (self.split or self.cf) else [None, None]
+        self._coarse_done = [False, False]
         # occupancy words of the inverse transform's level-1 tiles: decoder -> inverse transform (include/spiht_hip.h)
         nw = C.c_uint64()
         _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec.mid, codec._lv, C.byref(nw)))
@@ -295,7 +299,14 @@ class OverlappedCodec:
         cd = self.codec
         self.H.wait_event(self.ev_d[s])
         with cd._color():  # (the colour setting of H is put on around each transform call: H may serve other codecs too)
-            if self.split:
+            if self.cf:
+                self._coarse(s)
+                self._coarse_done[s] = False
+                _lib.check(cd.L.spiht_idwt_level1_flags_batch_f64(
+                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr),
+                    C.c_void_p(self.flags[s].ptr if self.flags[s] else None), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
+                    float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
+            elif self.split:
                 _lib.check(cd.L.spiht_idwt_level1_batch_f64(
                     self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr), self.B, cd.c, cd.H, cd.W,
                     cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
@@ -305,6 +316,17 @@ class OverlappedCodec:
                     cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p,
                     C.c_void_p(d_img_out)))
         self.H.record(self.ev_i[s])
+
+    def _coarse(self, s):
+        """coarse_first: levels level .. 2 of batch s's inverse transform on H (once)"""
+        cd = self.codec
+        if self._coarse_done[s]:
+            return
+        self.H.wait_event(self.ev_d[s])
+        _lib.check(cd.L.spiht_idwt_coarse_batch_f64(
+            self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
+            float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(self.approx[s].ptr)))
+        self._coarse_done[s] = True
 
     def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None, dec_src=None):
         """queue the round trip of one batch (device pointers as in BatchCodec.encode_device / decode_device).
@@ -317,9 +339,19 @@ class OverlappedCodec:
         q = float(cd.settings.quantization_scale)
         # H: front half of the encoder
         with cd._color():
-            _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
-                self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
-                vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
+            if self.cf:
+                _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
+                    self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
+                    vp(self.coeffs[s].ptr), None, None, vp(self.maxabs[s].ptr)))
+                if self._pending is not None:
+                    self._coarse(self._pending[0])
+                _lib.check(cd.L.spiht_pyramid_batch_i32(
+                    self.H.handle, vp(self.coeffs[s].ptr), B, cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"],
+                    vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), None))
+            else:
+                _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
+                    self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
+                    vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
         self.H.record(self.ev_a[s])
         # L: zeros back into the array batch i-2 was decoded into, once its inverse transform (queued on H by the
         # previous submit) has read it ...

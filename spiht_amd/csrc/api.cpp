@@ -1344,7 +1344,8 @@ extern "C" int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t 
 //   coarse: levels level..2 -> d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] (float64), the approximation level 1 starts from
 //   level1: d_rec + d_approx -> pixels.  With fewer than two levels the coarse part does nothing and d_approx is not read.
 static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int64_t B, int64_t c, int64_t H, int64_t W,
-                     int wavelet, int mode, int level, double q_scale, const double *channel_mults, double *d_img_out) {
+                     int wavelet, int mode, int level, double q_scale, const double *channel_mults, double *d_img_out,
+                     const uint32_t *d_flags = nullptr) {
     if (!ctx || !d_rec || (!d_approx && !d_img_out)) return SPIHT_ERR_ARG;
     CHK(check_img_args(wavelet, mode, B, c, H, W));
     if (B == 0) return SPIHT_OK;
@@ -1361,6 +1362,8 @@ static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int
     const int F = SPIHT_WAVELETS[wavelet].F;
     const size_t a_plane = ig.L >= 2 ? (size_t)(2 * ig.hs[2] - F + 2) * (size_t)(2 * ig.ws[2] - F + 2) : 0;
     const int chunk = (int)std::max<int64_t>(1, 65535 / c);
+    L1Flags fl;
+    const bool flagged = d_flags && !(ctx->color_on && c == 3) && l1flags_geometry(ig, F, &fl);
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         const int nb = (int)std::min<int64_t>(chunk, B - b0);
         const int32_t *rec = d_rec + (size_t)b0 * c * ig.enc_h * ig.enc_w;
@@ -1369,7 +1372,8 @@ static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int
             CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults, ap, ig.L, 2, nullptr));
         else
             CHK(dwt_inverse(ctx, rec, nb * (int)c, (int)c, ig, wavelet, q_scale, d_mults,
-                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, std::min(ig.L, 1), 1, ig.L >= 2 ? ap : nullptr));
+                            d_img_out + (size_t)b0 * c * ig.rec_H * ig.rec_W, std::min(ig.L, 1), 1, ig.L >= 2 ? ap : nullptr,
+                            flagged ? d_flags + (size_t)b0 * c * fl.gy * fl.gx : nullptr));
     }
     return SPIHT_OK;
 }
@@ -1385,6 +1389,15 @@ extern "C" int spiht_idwt_level1_batch_f64(spiht_ctx *ctx, const int32_t *d_rec,
     if (!d_img_out) return SPIHT_ERR_ARG;
     return idwt_part(ctx, d_rec, const_cast<double *>(d_approx), B, c, H, W, wavelet, mode, level, q_scale, channel_mults,
                      d_img_out);
+}
+
+// ... reading the decoder's occupancy words of the level-1 tiles (spiht_decode_lists_flags_batch_i32; NULL: reads everything)
+extern "C" int spiht_idwt_level1_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const double *d_approx, const uint32_t *d_flags,
+                                                 int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level,
+                                                 double q_scale, const double *channel_mults, double *d_img_out) {
+    if (!d_img_out) return SPIHT_ERR_ARG;
+    return idwt_part(ctx, d_rec, const_cast<double *>(d_approx), B, c, H, W, wavelet, mode, level, q_scale, channel_mults,
+                     d_img_out, d_flags);
 }
 
 extern "C" int spiht_idwt_approx_shape(int64_t H, int64_t W, int wavelet, int level, int64_t *a_h, int64_t *a_w) {

@@ -284,7 +284,8 @@ def test_overlapped_codec_matches_fused(oracle, shape):
 
 
 @pytest.mark.parametrize("opts", [dict(pair="forward"), dict(split_inverse=True), dict(pair="forward", split_inverse=True),
-                                  dict(u_early=False), dict(e_first=True, l_priority=1, u_early=False), dict(decoder_waves=12)])
+                                  dict(u_early=False), dict(e_first=True, l_priority=1, u_early=False), dict(decoder_waves=12),
+                                  dict(coarse_first=True), dict(l1_flags=False)])
 def test_overlapped_codec_schedule_variants(opts):
     """Every arrangement of the pipelined schedule (OverlappedCodec: what the decoder shares the GPU with, the inverse
     transform in two parts -- spiht_idwt_coarse_batch_f64 / spiht_idwt_level1_batch_f64 --, where the unscatter goes,
