@@ -154,8 +154,6 @@ struct D1Cover {
 
 #ifdef __HIPCC__
 // Rows 2r, 2r+1 of the packed array: 1 = two rows of 'ad' held by one wavefront, 2 = of 'da' / 'dd', 0 = neither.
-// Columns alike (1 = 'da', 2 = 'ad' / 'dd').  A node's block is covered iff both are non-zero and not both 1 (1 and 1 is
-// the approximation side of the array: off_h >= band height, off_w >= band width).
 __device__ __forceinline__ int d1_rows_covered(const D1Cover &v, uint32_t r) {
     const int R = 2 * (int)r;
     int oh, cls;
@@ -164,13 +162,15 @@ __device__ __forceinline__ int d1_rows_covered(const D1Cover &v, uint32_t r) {
     else return 0;
     return (uint32_t)oh % D1_ROWS != D1_ROWS - 1 ? cls : 0;
 }
-__device__ __forceinline__ int d1_cols_covered(const D1Cover &v, uint32_t c) {
-    const int Cc = 2 * (int)c;
-    int ow, cls;
-    if (Cc + 1 < v.lim_w) { ow = Cc; cls = 1; }
-    else if (Cc >= v.off_w && Cc + 1 - v.off_w < v.lim_w) { ow = Cc - v.off_w; cls = 2; }
-    else return 0;
-    return (uint32_t)ow % D1_COLS != D1_COLS - 1 ? cls : 0;
+// Columns 2c .. 2c+3 (the blocks of the two nodes c, c+1): 1 = four columns of 'da', 2 = of 'ad' / 'dd', 0 = neither.
+// A node's block is then in a level-1 band iff rows and columns are non-zero and not both 1 (1 and 1 is the approximation
+// side of the array: off_h >= band height, off_w >= band width).  Blocks whose two columns lie in two tiles (band column
+// = D1_COLS - 1 mod D1_COLS) are not told apart here: the pyramid pass writes those first (k_pyr_bcols).
+__device__ __forceinline__ int d1_cols4_in_band(const D1Cover &v, uint32_t c) {
+    const int C0 = 2 * (int)c;
+    if (C0 + 3 < v.lim_w) return 1;
+    if (C0 >= v.off_w && C0 + 3 - v.off_w < v.lim_w) return 2;
+    return 0;
 }
 #endif
 
