@@ -385,6 +385,25 @@ def test_level1_tile_occupancy_words(oracle, case):
                 assert not (staged & (fl[:, :, ty, tx] == 0)).any(), (ty, tx)
         if bpp <= 0.5:
             assert fl.mean() < 0.5, float(fl.mean())
+        # ... and for streams no encoder made: random bytes put values anywhere in the tree, padding cells included
+        rng = np.random.default_rng(17)
+        for trial in range(3):
+            junk = rng.integers(0, 256, (B, stride), dtype=np.uint8)
+            d_data.upload(junk)
+            d_nb.upload(np.array([stride - 3 * trial, stride // 2], np.uint64))
+            d_mn.upload(np.array([9 + trial, 6], np.uint8))
+            d_rec.zero()
+            _lib.check(L.spiht_decode_lists_flags_batch_i32(ctx.handle, vp(d_data.ptr), stride, vp(d_nb.ptr), vp(d_mn.ptr), B, c, H, W,
+                                                            cd.wid, cd.mid, cd._lv, vp(d_rec.ptr), vp(d_fl.ptr)))
+            two = []
+            for f in (d_fl.ptr, None):
+                d_img = DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64)
+                _lib.check(L.spiht_dequant_idwt_flags_batch_f64(ctx.handle, vp(d_rec.ptr), vp(f), B, c, H, W, cd.wid, cd.mid, cd._lv,
+                                                                float(s.quantization_scale), None, vp(d_img.ptr)))
+                ctx.synchronize()
+                two.append(d_img.download())
+                d_img.free()
+            assert np.array_equal(two[0], two[1]), trial
     for a in (d_data, d_nb, d_mn, d_rec, d_fl):
         a.free()
 
