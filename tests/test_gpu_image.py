@@ -729,3 +729,45 @@ def test_c_pipeline_matches_fused(cfg):
     pl.close()
     for d in d_imgs + d_recs + d_outs + d_nbits + d_maxn:
         d.free()
+
+
+@pytest.mark.gpu
+def test_c_caller_of_the_pipeline(tmp_path):
+    """INTEGRATION.md's C example for real: tests/native/pipeline_smoke.c, compiled with gcc against include/spiht_hip.h and
+    linked with libspiht_hip.so, runs the pipelined round trip with no Python in the process; its per-step checksums of
+    streams and decoded pictures equal those of the fused Python calls on the same pixels."""
+    import subprocess
+    import spiht_amd
+    from spiht_amd.batch import BatchCodec
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pipeline_smoke")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "native", "pipeline_smoke.c"),
+                           "-o", exe, "-L", os.path.join(root, "spiht_amd"), "-l:libspiht_hip.so", "-Wl,-rpath," + os.path.join(root, "spiht_amd")])
+    B, c, H, W, level, mb, steps = 3, 3, 96, 136, 3, 9000, 4
+    p = subprocess.run([exe] + [str(v) for v in (B, c, H, W, level, mb, steps)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("step")]
+    assert len(lines) == steps
+
+    def fnv(b, h=1469598103934665603):
+        for v in bytes(b):
+            h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    codec = BatchCodec(c, H, W, spiht_amd.SpihtSettings(), level, mb)
+    for s in range(steps):
+        t = np.arange(B * c * H * W, dtype=np.uint64)
+        x, y, k = t % W, (t // W) % H, t // (W * H)
+        hsh = ((t + 1) * np.uint64(2654435761) + np.uint64(s * 40503)) & np.uint64(0xFFFFFFFF)
+        v = (x * 3 + y * 5 + k * 17 + np.uint64(s * 29)) % 200 + (hsh >> np.uint64(28))
+        imgs = (v.astype(np.float64) / 255.0).reshape(B, c, H, W)
+        res = codec.encode(imgs)
+        hs = 1469598103934665603
+        for r in res:
+            hs = ((hs ^ fnv(r.encoded_bytes)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        dec = np.stack(codec.decode(res))
+        ln = lines[s]
+        assert int(ln[3], 16) == hs, (s, ln)
+        assert int(ln[5]) == min(mb, 8 * len(res[0].encoded_bytes)) or (int(ln[5]) + 7) // 8 == len(res[0].encoded_bytes)
+        assert int(ln[7]) == res[0].max_n
+        assert int(ln[9], 16) == fnv(np.ascontiguousarray(dec).tobytes()), s
