@@ -47,7 +47,7 @@ typedef struct spiht_ctx spiht_ctx;
 
 const char *spiht_strerror(int status);
 const char *spiht_last_hip_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change and on every round that adds entry points (now 2). */
 int spiht_abi_version(void);
 
 /* One context per (process, GPU): device id, streams, scratch.  Thread-safe per context

@@ -34,6 +34,8 @@ typedef struct {
     const char *name;
     int F;
     double dec_lo[MAXF], dec_hi[MAXF], rec_lo[MAXF], rec_hi[MAXF];
+    float dec_lo_f[MAXF], dec_hi_f[MAXF];  /* the analysis filters PyWavelets uses on float32 input: the doubles rounded, except
+                                            * for the coiflets, which it builds from a float table (wavelets.c) */
 } wavelet_t;
 
 /* pywt.Wavelet(name).filter_bank, repr(float), of every discrete wavelet with at most 20 taps (generated
@@ -460,17 +462,63 @@ int orc_waverec2_array_mode(const double *arr, int64_t c, int64_t H, int64_t W, 
  * first the taps that read the extension, nearest first (filter index i-N down to 0), then the others
  * ascending.  Checked against pywt 1.1.1: bit-identical float32 lines (tests/golden: wrapper32).
  * ------------------------------------------------------------------------------------------------ */
+/* ext_value in single precision (the template instantiated with float: every intermediate is a float) */
+static float ext_value_f(const float *x, int64_t N, int64_t sx, int64_t i, int mode) {
+    if (mode == MODE_PERIODIZATION) {
+        int64_t Np = N + (N & 1), m = i % Np;
+        if (m < 0) m += Np;
+        return x[(m < N ? m : N - 1) * sx];
+    }
+    if (i >= 0 && i < N) return x[i * sx];
+    if (mode == MODE_SMOOTH) {
+        if (N < 2) return x[0];
+        volatile float df, pr, v;
+        if (i < 0) { df = x[0] - x[sx]; pr = (float)(-i) * df; v = x[0] + pr; return v; }
+        df = x[(N - 1) * sx] - x[(N - 2) * sx]; pr = (float)(i - N + 1) * df; v = x[(N - 1) * sx] + pr;
+        return v;
+    }
+    if (mode == MODE_ANTISYMMETRIC) {
+        int64_t P = 2 * N, m = i % P;
+        if (m < 0) m += P;
+        int64_t b = (i - m) / N + (m >= N);
+        const float v = x[(m < N ? m : P - 1 - m) * sx];
+        return (b & 1) ? -v : v;
+    }
+    if (N < 2) return x[0];
+    const int left = i < 0;
+    int64_t d = left ? -i : i - N + 1;
+    volatile float e = left ? x[0] : x[(N - 1) * sx];
+    int away = 1;
+    for (;;) {
+        const int64_t k = d <= N - 1 ? d : N - 1;
+        const int from_left = left ? away : !away;
+        volatile float dl = from_left ? x[k * sx] - x[0] : x[(N - 1 - k) * sx] - x[(N - 1) * sx];
+        volatile float v = away ? e - dl : e + dl;
+        if (d <= N - 1) return v;
+        e = v;
+        d -= N - 1;
+        away = !away;
+    }
+}
+
 static void dwt_line_f(const float *x, int64_t N, int64_t sx, const float *lo, const float *hi, int F, int mode,
                        float *ca, float *cd, int64_t so) {
-    int64_t L = (N + F - 1) / 2;
+    const int per = mode == MODE_PERIODIZATION;
+    int64_t L = per ? (N + 1) / 2 : (N + F - 1) / 2;
     for (int64_t o = 0; o < L; o++) {
         volatile float a = 0.0f, d = 0.0f; /* volatile: no contraction, no reassociation, no excess precision */
-        /* constant-edge mode: pywt adds the replicated-edge taps in ascending order too, i.e. plain ascending everywhere */
-        int64_t i = 2 * o + 1, jb = (i >= N && mode != MODE_CONSTANT) ? i - N : -1;
+        /* constant-edge mode: pywt adds the replicated-edge taps in ascending order too, i.e. plain ascending everywhere
+         * (and so does smooth) */
+        int64_t i = per ? F / 2 + 2 * o : 2 * o + 1, jb = (i >= N && mode != MODE_CONSTANT && mode != MODE_SMOOTH) ? i - N : -1;
         for (int s = 0; s < F; s++) {
             int j = s <= jb ? (int)(jb - s) : s;
-            int64_t idx = ext_index(i - j, N, mode);
-            float v = idx < 0 ? 0.0f : x[idx * sx];
+            float v;
+            if (mode >= MODE_SMOOTH) {
+                v = ext_value_f(x, N, sx, i - j, mode);
+            } else {
+                int64_t idx = ext_index(i - j, N, mode);
+                v = idx < 0 ? 0.0f : x[idx * sx];
+            }
             volatile float pa = lo[j] * v, pd = hi[j] * v;
             a = a + pa;
             d = d + pd;
@@ -486,10 +534,10 @@ int orc_wavedec2_array_f32(const float *img, int64_t c, int64_t H, int64_t W, in
     const wavelet_t *wv = &WAVELETS[wid];
     int F = wv->F;
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
-    int L = orc_geometry(H, W, F, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
+    int L = orc_geometry_mode(H, W, F, mode, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
     /* (inputs shorter than the filter take the same order of additions: checked against PyWavelets, tests/golden) */
     float lo[32], hi[32];
-    for (int j = 0; j < F; j++) { lo[j] = (float)wv->dec_lo[j]; hi[j] = (float)wv->dec_hi[j]; }
+    for (int j = 0; j < F; j++) { lo[j] = wv->dec_lo_f[j]; hi[j] = wv->dec_hi_f[j]; }
     memset(arr, 0, sizeof(float) * c * eh * ew);
     int64_t offh[64], offw[64];
     int64_t ah = ll_h, aw = ll_w;

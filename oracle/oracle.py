@@ -271,7 +271,7 @@ def wavedec2_array_f32(img, wavelet, mode, level):
     """the float32 transform PyWavelets runs on float32 / float16 input -> float32 [c,enc_h,enc_w]"""
     img = np.ascontiguousarray(img, dtype=np.float32)
     c, H, W = img.shape
-    g = geometry(H, W, wavelet, level)
+    g = geometry(H, W, wavelet, level, mode)
     arr = np.empty((c, g["enc_h"], g["enc_w"]), dtype=np.float32)
     L = lib()
     L.orc_wavedec2_array_f32.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]

@@ -33,8 +33,8 @@ int spiht_launch_nbits_to_nbytes(const uint64_t *d_nbits, int B, uint64_t *d_nby
 int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, const double *A, const double *M, double p,
                         hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
-int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double *t_lo, double *t_hi, double *b_aa, double *b_ad, double *b_da,
-                               double *b_dd, hipStream_t st);
+int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, void *t_lo, void *t_hi, void *b_aa, void *b_ad, void *b_da,
+                               void *b_dd, hipStream_t st);
 int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
@@ -352,7 +352,7 @@ extern "C" const char *spiht_strerror(int s) {
     }
 }
 extern "C" const char *spiht_last_hip_error(void) { return g_hip_err.c_str(); }
-extern "C" int spiht_abi_version(void) { return 1; }
+extern "C" int spiht_abi_version(void) { return 2; }  // 2: round 3 (pipeline, occupancy words, options, geometry_mode, every wavelet / mode)
 
 extern "C" int spiht_ctx_create(int device, spiht_ctx **out) { return spiht_ctx_create_priority(device, 0, out); }
 
@@ -1064,7 +1064,6 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
     if (f32 && ig.L == 0) return SPIHT_ERR_ARG;
     bool color = ctx->color_on && c == 3;
     if (color && f32) return SPIHT_ERR_ARG;  // the colour model change is float64 (as colour-science's)
-    if (f32 && mode >= SPIHT_MODE_SMOOTH) return SPIHT_ERR_ARG;  // (single precision: the five index-map modes only)
     if (color && mode >= SPIHT_MODE_SMOOTH && ig.L > 0) {
         // the two-pass level has no colour form: the colour model change as a pass of its own in front of it
         const size_t npix = (size_t)ig.hs[0] * ig.ws[0];
@@ -1132,30 +1131,35 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         if (color && l == 1) { a.color = 1; a.col = ctx->col_fwd; }
         memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
         memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
+        memcpy(a.lo_f, wv.dec_lo_f, sizeof(float) * wv.F);
+        memcpy(a.hi_f, wv.dec_hi_f, sizeof(float) * wv.F);
         // (two levels at least: the parents of the level-1 cells are then depth-1 nodes outside the root block)
         if (l == 1 && ig.L >= 2 && d_dmsb && cov && emit_on && !f32 && !a.color) {
             a.dmsb = d_dmsb;
             spiht_dwt_d1_cover(&a, cov);
         }
         if (mode >= SPIHT_MODE_SMOOTH) {
-            // smooth / antisymmetric / antireflect: two plain passes through an intermediate (dwt.hip: k_dwt_axis_ext), a few
-            // planes at a time so that the intermediates stay under a gigabyte
+            // smooth / antisymmetric / antireflect / periodization: two plain passes through an intermediate (dwt.hip:
+            // k_dwt_axis_ext), a few planes at a time so that the intermediates stay under a gigabyte; in the pixels' precision
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
-            const size_t per_plane = ((size_t)2 * a.out_h * a.in_w + (size_t)4 * a.out_h * a.out_w) * 8;
+            const size_t esz = f32 ? 4 : 8;
+            const size_t n_t = (size_t)a.out_h * a.in_w, n_b = (size_t)a.out_h * a.out_w;  // elements per plane
+            const size_t per_plane = (2 * n_t + 4 * n_b) * esz;
             int pc = (int)std::max<size_t>(1, ((size_t)1 << 30) / per_plane);
             pc = std::max(c, pc / c * c);  // whole images: the max|coefficient| word and the channel scale go by plane / c, plane % c
             CHK(ensure(ctx, ctx->exttmp, per_plane * (size_t)std::min(pc, planes)));
             for (int p0 = 0; p0 < planes; p0 += pc) {
                 const int np = std::min(pc, planes - p0);
                 DwtKArgs b = a;
-                b.in = a.in + (size_t)p0 * a.in_h * a.in_w;
-                if (b.ll_out) b.ll_out = a.ll_out + (size_t)p0 * a.out_h * a.out_w;
+                b.in = (const double *)((const char *)a.in + (size_t)p0 * a.in_h * a.in_w * esz);
+                if (b.ll_out) b.ll_out = (double *)((char *)a.ll_out + (size_t)p0 * n_b * esz);
                 b.coeffs = a.coeffs + (size_t)p0 * a.enc_h * a.enc_w;
                 if (b.maxabs) b.maxabs = a.maxabs + p0 / c;
-                double *t_lo = (double *)ctx->exttmp.p, *t_hi = t_lo + (size_t)np * a.out_h * a.in_w;
-                double *b_aa = t_hi + (size_t)np * a.out_h * a.in_w, *b_ad = b_aa + (size_t)np * a.out_h * a.out_w;
-                double *b_da = b_ad + (size_t)np * a.out_h * a.out_w, *b_dd = b_da + (size_t)np * a.out_h * a.out_w;
-                LAUNCHCHK(spiht_launch_dwt_level_ext(&b, np, t_lo, t_hi, b_aa, b_ad, b_da, b_dd, ctx->stream));
+                char *base = (char *)ctx->exttmp.p;
+                void *t_lo = base, *t_hi = base + (size_t)np * n_t * esz;
+                char *bb = base + 2 * (size_t)np * n_t * esz;
+                LAUNCHCHK(spiht_launch_dwt_level_ext(&b, np, t_lo, t_hi, bb, bb + (size_t)np * n_b * esz, bb + 2 * (size_t)np * n_b * esz,
+                                                     bb + 3 * (size_t)np * n_b * esz, ctx->stream));
             }
         } else {
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);

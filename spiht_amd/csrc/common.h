@@ -210,6 +210,7 @@ struct DwtKArgs {
                            // 2x2 block lies inside one tile and one band (D1Cover; the pyramid pass computes the rest)
     double q;
     double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // dec_lo, dec_hi
+    float lo_f[SPIHT_MAX_TAPS], hi_f[SPIHT_MAX_TAPS];  // ... as PyWavelets' single-precision transform has them (f32 levels)
     int32_t color, pad2;   // level 1 of a 3-channel image with the colour model change on its loads (k_dwt1_color)
     Color3 col;
 };

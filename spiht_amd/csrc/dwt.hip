@@ -385,13 +385,13 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
     const int oh0 = (int)tby * DW32_TH, ow0 = (int)tbx * DW_TW;
     const float *__restrict__ in = reinterpret_cast<const float *>(a.in) + (size_t)plane * a.in_h * a.in_w;
     const int tid = threadIdx.x;
-    float flo[F], fhi[F];
+    float flo[F], fhi[F];  // (PyWavelets' single-precision filters: not always the doubles rounded -- the coiflets)
 #pragma unroll
-    for (int j = 0; j < F; j++) { flo[j] = (float)a.lo[j]; fhi[j] = (float)a.hi[j]; }
+    for (int j = 0; j < F; j++) { flo[j] = a.lo_f[j]; fhi[j] = a.hi_f[j]; }
 
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
     if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
-    if (tid < F) { s_flo[tid] = (float)a.lo[tid]; s_fhi[tid] = (float)a.hi[tid]; }
+    if (tid < F) { s_flo[tid] = a.lo_f[tid]; s_fhi[tid] = a.hi_f[tid]; }
     __shared__ uint32_t s_amax;
     if (tid == 0) s_amax = 0;
     __syncthreads();
@@ -830,7 +830,8 @@ void k_dwt1_color(DwtKArgs a, uint32_t gx, uint32_t gy) {                       
 // (a path nobody's headline runs on; the tiled kernel above serves the index-map modes).  Summation order as pywt's
 // downsampling_convolution: taps ascending, except that on the right overhang of an input at least as long as the filter
 // the taps that read the extension come first, nearest first -- smooth, like constant, keeps ascending order there too.
-__device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, int i, int mode) {
+template <typename T>
+__device__ __forceinline__ T ext_value(const T *x, int N, size_t sx, int i, int mode) {
     if (mode == 8) {  // periodization: the signal, made even by repeating its last sample, continued periodically
         const int Np = N + (N & 1);
         int m = i % Np;
@@ -840,28 +841,28 @@ __device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, i
     if (i >= 0 && i < N) return x[(size_t)i * sx];
     if (mode == 5) {  // smooth: the straight line through the two samples at the edge
         if (N < 2) return x[0];
-        if (i < 0) return x[0] + (double)(-i) * (x[0] - x[sx]);
-        return x[(size_t)(N - 1) * sx] + (double)(i - N + 1) * (x[(size_t)(N - 1) * sx] - x[(size_t)(N - 2) * sx]);
+        if (i < 0) return x[0] + (T)(-i) * (x[0] - x[sx]);
+        return x[(size_t)(N - 1) * sx] + (T)(i - N + 1) * (x[(size_t)(N - 1) * sx] - x[(size_t)(N - 2) * sx]);
     }
     if (mode == 6) {  // antisymmetric: half-sample mirror image, every other block of N samples negated
         const int P = 2 * N;
         int m = i % P;
         if (m < 0) m += P;
         const int blk = (i - m) / N + (m >= N ? 1 : 0);
-        const double v = x[(size_t)(m < N ? m : P - 1 - m) * sx];
+        const T v = x[(size_t)(m < N ? m : P - 1 - m) * sx];
         return (blk & 1) ? -v : v;
     }
     // antireflect: whole-sample mirror image through the edge VALUE; the value a block ends on is the next block's edge
     if (N < 2) return x[0];
     const bool left = i < 0;
     int d = left ? -i : i - N + 1;
-    double e = left ? x[0] : x[(size_t)(N - 1) * sx];
+    T e = left ? x[0] : x[(size_t)(N - 1) * sx];
     bool away = true;  // the first block walks away from the edge it started at and subtracts; the next one comes back and adds
     for (;;) {
         const int k = d <= N - 1 ? d : N - 1;
         const bool from_left = left ? away : !away;
-        const double dlt = from_left ? x[(size_t)k * sx] - x[0] : x[(size_t)(N - 1 - k) * sx] - x[(size_t)(N - 1) * sx];
-        const double v = away ? e - dlt : e + dlt;
+        const T dlt = from_left ? x[(size_t)k * sx] - x[0] : x[(size_t)(N - 1 - k) * sx] - x[(size_t)(N - 1) * sx];
+        const T v = away ? e - dlt : e + dlt;
         if (d <= N - 1) return v;
         e = v;
         d -= N - 1;
@@ -870,16 +871,19 @@ __device__ __forceinline__ double ext_value(const double *x, int N, size_t sx, i
 }
 
 // one analysis pass along one axis: out position o of line `line` of plane `plane`.  n_lines lines of length N, element
-// stride sx, line stride sl; outputs: lo / hi [plane][L][n_lines] laid out with the same strides roles (so, sol)
+// stride sx, line stride sl; outputs: lo / hi [plane][L][n_lines] laid out with the same strides roles (so, sol).
+// T = float: the single-precision transform PyWavelets runs on float32 / float16 pixels (its own filter values).
 struct DwtAxisArgs {
     int32_t F, mode, N, L, n_lines, planes;
     int32_t i0, pad;             // output o reads the window that ends at sample 2 o + i0: 1, or F / 2 under periodization
     size_t sx, sl, plane_in;     // input: element stride along the axis, stride between lines, plane stride
     size_t so, sol, plane_out;   // output alike
-    const double *in;
-    double *lo, *hi;
+    const void *in;
+    void *lo, *hi;
     double flo[SPIHT_MAX_TAPS], fhi[SPIHT_MAX_TAPS];
+    float flo_f[SPIHT_MAX_TAPS], fhi_f[SPIHT_MAX_TAPS];
 };
+template <typename T>
 __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t per_plane = (size_t)a.L * a.n_lines;
@@ -890,30 +894,32 @@ __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
     int o, line;
     if (a.so == 1) { line = (int)(r / a.L); o = (int)(r - (size_t)line * a.L); }
     else { o = (int)(r / a.n_lines); line = (int)(r - (size_t)o * a.n_lines); }
-    const double *x = a.in + (size_t)plane * a.plane_in + (size_t)line * a.sl;
+    const T *x = reinterpret_cast<const T *>(a.in) + (size_t)plane * a.plane_in + (size_t)line * a.sl;
     const int i = 2 * o + a.i0;
     const int jb = (i >= a.N && a.mode != 5) ? i - a.N : -1;
-    double sa = 0.0, sd = 0.0;
+    T sa = 0, sd = 0;
     for (int s2 = 0; s2 < a.F; s2++) {
         const int j = s2 <= jb ? jb - s2 : s2;
-        const double v = ext_value(x, a.N, a.sx, i - j, a.mode);
-        sa += a.flo[j] * v;
-        sd += a.fhi[j] * v;
+        const T v = ext_value<T>(x, a.N, a.sx, i - j, a.mode);
+        const T fl = sizeof(T) == 4 ? (T)a.flo_f[j] : (T)a.flo[j], fh = sizeof(T) == 4 ? (T)a.fhi_f[j] : (T)a.fhi[j];
+        sa += fl * v;
+        sd += fh * v;
     }
     const size_t oo = (size_t)plane * a.plane_out + (size_t)line * a.sol + (size_t)o * a.so;
-    a.lo[oo] = sa;
-    a.hi[oo] = sd;
+    reinterpret_cast<T *>(a.lo)[oo] = sa;
+    reinterpret_cast<T *>(a.hi)[oo] = sd;
 }
 // quantise + pack the four sub-bands of a level computed by the two passes: aa / ad from the low rows, da / dd from the high rows
 struct DwtPackArgs {
     int32_t c, out_h, out_w, off_h, off_w, enc_h, enc_w, last, planes, pad;
-    const double *aa, *ad, *da, *dd;   // [planes, out_h, out_w]
-    double *ll_out;
+    const void *aa, *ad, *da, *dd;   // [planes, out_h, out_w]
+    void *ll_out;
     int32_t *coeffs;
     const double *mults;
     uint32_t *maxabs;
     double q;
 };
+template <typename T>
 __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t per = (size_t)a.out_h * a.out_w;
@@ -924,14 +930,21 @@ __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
         const int oh = (int)(r / a.out_w), ow = (int)(r - (size_t)oh * a.out_w);
         const bool has_m = a.mults != nullptr;
         const double mk = has_m ? a.mults[plane % a.c] : 1.0;
+        const float qf = (float)a.q;
+        auto qz = [&](T v) -> int32_t {  // the wrapper's arithmetic in the array's precision (spiht_wrapper.py:167-172, :9-11)
+            if (sizeof(T) == 4) return quant_f32((float)v, mk, a.q, qf, has_m);
+            return quant((double)v, mk, a.q, has_m);
+        };
         int32_t *co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
-        const int32_t qad = quant(a.ad[t], mk, a.q, has_m), qda = quant(a.da[t], mk, a.q, has_m), qdd = quant(a.dd[t], mk, a.q, has_m);
+        const T *aa = reinterpret_cast<const T *>(a.aa), *ad = reinterpret_cast<const T *>(a.ad);
+        const T *da = reinterpret_cast<const T *>(a.da), *dd = reinterpret_cast<const T *>(a.dd);
+        const int32_t qad = qz(ad[t]), qda = qz(da[t]), qdd = qz(dd[t]);
         if (a.last) {
-            const int32_t qaa = quant(a.aa[t], mk, a.q, has_m);
+            const int32_t qaa = qz(aa[t]);
             co[(size_t)oh * a.enc_w + ow] = qaa;
             amax = iabs_u(qaa);
         } else {
-            a.ll_out[t] = a.aa[t];
+            reinterpret_cast<T *>(a.ll_out)[t] = aa[t];
         }
         co[(size_t)oh * a.enc_w + a.off_w + ow] = qad;
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
@@ -940,37 +953,42 @@ __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
         if (a.maxabs != nullptr && amax) atomicMax(&a.maxabs[plane / a.c], amax);
     }
 }
-// tmp: 6 arrays of planes*out_h*in_w (2) and planes*out_h*out_w (4) doubles, carved by the caller
-extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, double *t_lo, double *t_hi, double *b_aa, double *b_ad,
-                                          double *b_da, double *b_dd, hipStream_t st) {
+// tmp: 6 arrays of planes*out_h*in_w (2) and planes*out_h*out_w (4) elements (float when a->f32), carved by the caller
+extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, void *t_lo, void *t_hi, void *b_aa, void *b_ad,
+                                          void *b_da, void *b_dd, hipStream_t st) {
     DwtAxisArgs x;
     memset(&x, 0, sizeof(x));
     x.F = a->F; x.mode = a->mode; x.planes = planes;
     x.i0 = a->mode == 8 ? a->F / 2 : 1;
-    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; }
+    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; x.flo_f[j] = a->lo_f[j]; x.fhi_f[j] = a->hi_f[j]; }
+    const bool f32 = a->f32 != 0;
+    auto axis = [&](size_t n) {
+        if (f32) hipLaunchKernelGGL(k_dwt_axis_ext<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+        else hipLaunchKernelGGL(k_dwt_axis_ext<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    };
     // axis -2: lines = columns
     x.N = a->in_h; x.L = a->out_h; x.n_lines = a->in_w;
     x.sx = (size_t)a->in_w; x.sl = 1; x.plane_in = (size_t)a->in_h * a->in_w;
     x.so = (size_t)a->in_w; x.sol = 1; x.plane_out = (size_t)a->out_h * a->in_w;
     x.in = a->in; x.lo = t_lo; x.hi = t_hi;
-    size_t n = (size_t)planes * x.L * x.n_lines;
-    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    axis((size_t)planes * x.L * x.n_lines);
     // axis -1 on the low rows, then on the high rows: lines = rows
     x.N = a->in_w; x.L = a->out_w; x.n_lines = a->out_h;
     x.sx = 1; x.sl = (size_t)a->in_w; x.plane_in = (size_t)a->out_h * a->in_w;
     x.so = 1; x.sol = (size_t)a->out_w; x.plane_out = (size_t)a->out_h * a->out_w;
-    n = (size_t)planes * x.L * x.n_lines;
+    const size_t n = (size_t)planes * x.L * x.n_lines;
     x.in = t_lo; x.lo = b_aa; x.hi = b_ad;
-    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    axis(n);
     x.in = t_hi; x.lo = b_da; x.hi = b_dd;
-    hipLaunchKernelGGL(k_dwt_axis_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
+    axis(n);
     DwtPackArgs p;
     memset(&p, 0, sizeof(p));
     p.c = a->c; p.out_h = a->out_h; p.out_w = a->out_w; p.off_h = a->off_h; p.off_w = a->off_w; p.enc_h = a->enc_h; p.enc_w = a->enc_w;
     p.last = a->last; p.planes = planes;
     p.aa = b_aa; p.ad = b_ad; p.da = b_da; p.dd = b_dd;
     p.ll_out = a->ll_out; p.coeffs = a->coeffs; p.mults = a->mults; p.maxabs = a->maxabs; p.q = a->q;
-    hipLaunchKernelGGL(k_dwt_pack_ext, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    if (f32) hipLaunchKernelGGL(k_dwt_pack_ext<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_dwt_pack_ext<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
     return (int)hipGetLastError();
 }
 

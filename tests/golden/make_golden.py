@@ -397,6 +397,35 @@ def part_modes():
     print("wrote modes_pywt.npz:", len(cases), "cases; pywt", pywt.__version__)
 
 
+def part_modes32():
+    """the same four modes on float32 pixels (PyWavelets then transforms in single precision): coefficient arrays, every
+    bit, and the int32 array the wrapper's float32 quantisation makes of them -> modes32_pywt.npz"""
+    import pywt
+    rng = np.random.default_rng(77)
+    out = {"pywt_version": np.array(pywt.__version__)}
+    i = 0
+    # (reflect with the coiflets: PyWavelets builds their single-precision filters from a float table -- not the doubles rounded)
+    for mode in ["smooth", "antisymmetric", "antireflect", "periodization", "reflect"]:
+        for j, wv in enumerate(["bior2.2", "bior4.4", "db2", "sym4", "haar", "coif1"] if mode != "reflect" else ["coif1", "coif2", "coif3"]):
+            F = pywt.Wavelet(wv).dec_len
+            H, W = int(rng.integers(max(3, F - 2), 3 * F + 20)), int(rng.integers(max(3, F - 2), 3 * F + 20))
+            lv = 1 + j % 3
+            img = synth_image(800 + i, 1 + j % 2, H, W).astype(np.float32)
+            arr, _ = pywt.coeffs_to_array(pywt.wavedec2(img, wavelet=wv, level=lv, mode=mode), axes=(-2, -1))
+            assert arr.dtype == np.float32
+            p = "c%d_" % i
+            out[p + "img"] = img
+            out[p + "arr"] = arr
+            out[p + "quant"] = np.ascontiguousarray((arr * 50.0).astype(np.int32))
+            out[p + "wavelet"] = np.array(wv)
+            out[p + "mode"] = np.array(mode)
+            out[p + "level"] = np.array(lv)
+            i += 1
+    out["ncases"] = np.array(i)
+    np.savez_compressed(os.path.join(HERE, "modes32_pywt.npz"), **out)
+    print("wrote modes32_pywt.npz:", i, "cases; pywt", pywt.__version__)
+
+
 def part_short():
     """inputs SHORTER than the filter (levels above pywt.dwt_max_level: PyWavelets warns and transforms them all the same,
     and so does the reference, spiht_wrapper.py:163): one and two levels, all eight extension modes in float64, the five
@@ -432,4 +461,4 @@ def part_short():
 
 if __name__ == "__main__":
     {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32,
-     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes, "short": part_short}[sys.argv[1]]()
+     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes, "modes32": part_modes32, "short": part_short}[sys.argv[1]]()

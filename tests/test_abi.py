@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(L, s), "libspiht_hip.so does not export %s" % s
     assert sorted(_lib.SYMBOLS) == declared
-    assert L.spiht_abi_version() == 1
+    assert L.spiht_abi_version() == 2
 
 
 def test_package_surface_matches_reference_init():

@@ -488,8 +488,6 @@ def test_computed_extension_modes(oracle):
         assert np.abs(d2[:, :131, :203] - imgs[1]).mean() < 0.25
     with pytest.raises(ValueError):
         spiht_amd.encode_image(imgs[0], spiht_amd.SpihtSettings(mode="nonsense"), 2)
-    with pytest.raises(ValueError):  # single precision: the index-map modes only
-        spiht_amd.encode_image(imgs[0].astype(np.float32), spiht_amd.SpihtSettings(mode="smooth"), 2)
 
 
 def _gpu_dwt_f32(img, wavelet, mode, level, q):
@@ -500,7 +498,7 @@ def _gpu_dwt_f32(img, wavelet, mode, level, q):
     wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
     v = [C.c_int64() for _ in range(6)]
     lv = C.c_int()
-    _lib.check(L.spiht_geometry(H, W, wid, level, C.byref(lv), *[C.byref(t) for t in v]))
+    _lib.check(L.spiht_geometry_mode(H, W, wid, mid, level, C.byref(lv), *[C.byref(t) for t in v]))
     out = np.empty((B, c, v[2].value, v[3].value), np.int32)
     d_in, d_out = ctx.alloc(img.nbytes), ctx.alloc(out.nbytes)
     try:
@@ -540,3 +538,23 @@ def test_inputs_shorter_than_the_filter(oracle):
     g = oracle.geometry(40, 56, "bior6.8", 4)
     ref_bytes, ref_n = oracle.encode(oracle.quantize_f32(arr, 50.0), g["ll_h"], g["ll_w"], 30000)[:2]
     assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n
+
+
+def test_single_precision_computed_modes_and_coiflets(oracle):
+    """float32 pixels x the modes that compute their extension, periodization, and the coiflets' own single-precision filters:
+    the int32 array the GPU hands to the coder against PyWavelets 1.1.1 (tests/golden/modes32_pywt.npz), and a whole
+    encode_image against the oracle."""
+    import spiht_amd
+    from test_oracle import modes32_cases
+    n = 0
+    for cs in modes32_cases():
+        got = _gpu_dwt_f32(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], 50.0)[0]
+        bad = np.argwhere(got != cs["quant"])
+        assert len(bad) == 0, (cs["wavelet"], cs["mode"], cs["img"].shape, len(bad), bad[:3])
+        n += 1
+    assert n == 27
+    img = synth_image(9, 3, 70, 93).astype(np.float32)
+    for wv, mode in (("coif2", "smooth"), ("db3", "periodization"), ("coif1", "reflect")):
+        enc = spiht_amd.encode_image(img, spiht_amd.SpihtSettings(wavelet=wv, mode=mode), level=2, max_bits=40000)
+        ref_bytes, ref_n, _ = oracle.encode_image(img, wv, mode, 2, 50.0, None, 40000)
+        assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n, (wv, mode)

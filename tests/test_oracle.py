@@ -432,3 +432,26 @@ def test_inputs_shorter_than_the_filter_match_pywt(oracle):
         assert np.array_equal(arr.view(np.uint8), cs["arr"].view(np.uint8)), (cs["wavelet"], cs["mode"], cs["img"].shape, cs["img"].dtype)
         n[str(arr.dtype)] += 1
     assert n["float64"] >= 100 and n["float32"] >= 60
+
+
+def modes32_cases():
+    z = np.load(os.path.join(GOLD, "modes32_pywt.npz"))
+    for i in range(int(z["ncases"])):
+        p = "c%d_" % i
+        yield dict(img=z[p + "img"], arr=z[p + "arr"], quant=z[p + "quant"], wavelet=str(z[p + "wavelet"]), mode=str(z[p + "mode"]),
+                   level=int(z[p + "level"]))
+
+
+def test_single_precision_computed_modes_and_coiflets_match_pywt(oracle):
+    """float32 pixels through smooth / antisymmetric / antireflect / periodization, and through the coiflets -- whose
+    single-precision filters PyWavelets builds from a float table (not the doubles rounded: csrc/wavelets.h carries them as
+    exact hex floats, read off PyWavelets' own transform of a unit impulse) -- against PyWavelets 1.1.1
+    (tests/golden/modes32_pywt.npz): the float32 coefficient array in every bit and the wrapper's float32 quantisation."""
+    n = 0
+    for cs in modes32_cases():
+        arr, _ = oracle.wavedec2_array_f32(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
+        assert arr.shape == cs["arr"].shape
+        assert np.array_equal(arr.view(np.uint32), cs["arr"].view(np.uint32)), (cs["wavelet"], cs["mode"], cs["level"])
+        assert np.array_equal(oracle.quantize_f32(arr, 50.0), cs["quant"])
+        n += 1
+    assert n == 27
