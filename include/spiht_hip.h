@@ -35,10 +35,10 @@ enum {
 /* signal extension modes of the DWT (pywt names) */
 enum { SPIHT_MODE_REFLECT = 0, SPIHT_MODE_SYMMETRIC = 1, SPIHT_MODE_PERIODIC = 2, SPIHT_MODE_ZERO = 3,
        SPIHT_MODE_CONSTANT = 4,
-       /* the modes whose extended samples are computed, not picked: a slower two-pass forward transform, float64 pixels */
+       /* the modes whose extended samples are computed, not picked: a slower two-pass forward transform */
        SPIHT_MODE_SMOOTH = 5, SPIHT_MODE_ANTISYMMETRIC = 6, SPIHT_MODE_ANTIREFLECT = 7,
        /* another length rule: ceil(n / 2) coefficients per level, 2 n samples back (spiht_geometry_mode); two-pass in both
-        * directions, float64 pixels */
+        * directions */
        SPIHT_MODE_PERIODIZATION = 8 };
 
 #define SPIHT_MAX_BITS_UNLIMITED 0xFFFFFFFFFFFFFFFFull
@@ -147,10 +147,12 @@ int spiht_decode_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, uint64_t slot_
 
 /* Geometry of the packed coefficient array for an H x W image (wrapper:92-139, pywt.wavedecn_shapes).
  * level < 0 means "None" (pywt's maximum useful level).  Any out pointer may be NULL. */
-/* Every discrete wavelet of PyWavelets with at most 20 taps (the reference hands SpihtSettings.wavelet to pywt as it is,
- * spiht_wrapper.py:163, :276): haar, db1-10, sym2-10, coif1-3, bior / rbio 1.1 ... 6.8 (csrc/wavelets.h, generated from
- * PyWavelets by tools/gen_wavelets.py).  Ids are positions in that table: bior2.2 = 0, bior4.4 = 1, bior6.8 = 2, haar = 3. */
-int spiht_wavelet_id(const char *name);           /* < 0 if unknown (or longer than 20 taps) */
+/* Every discrete wavelet of PyWavelets, 106 names (the reference hands SpihtSettings.wavelet to pywt as it is,
+ * spiht_wrapper.py:163, :276): haar, db1-38, sym2-20, coif1-17, bior / rbio 1.1 ... 6.8, dmey (csrc/wavelets.h, generated
+ * from PyWavelets by tools/gen_wavelets.py).  Filters of up to 20 taps run in the tiled level kernels; longer ones (up to
+ * 102 taps) in the plain two-pass levels, their filters read from device memory.  Ids are positions in that table:
+ * bior2.2 = 0, bior4.4 = 1, bior6.8 = 2, haar = 3. */
+int spiht_wavelet_id(const char *name);           /* < 0 if unknown */
 int spiht_wavelet_taps(int wavelet);              /* filter length (pywt dec_len); < 0: no such id */
 int spiht_mode_id(const char *name);              /* the pywt names of the nine modes above; <0 if unknown */
 int spiht_geometry(int64_t H, int64_t W, int wavelet, int level, int *level_used, int64_t *ll_h, int64_t *ll_w,

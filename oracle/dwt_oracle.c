@@ -28,7 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXF 20
+#define MAXF 102
 
 typedef struct {
     const char *name;
@@ -38,7 +38,7 @@ typedef struct {
                                             * for the coiflets, which it builds from a float table (wavelets.c) */
 } wavelet_t;
 
-/* pywt.Wavelet(name).filter_bank, repr(float), of every discrete wavelet with at most 20 taps (generated
+/* pywt.Wavelet(name).filter_bank, repr(float), of every discrete wavelet, up to 102 taps (generated
  * from PyWavelets 1.1.1 by tools/gen_wavelets.py oracle; cross-checked against the library by tests/golden/make_golden.py) */
 static const wavelet_t WAVELETS[] = {
 #include "wavelets_table.h"
@@ -536,7 +536,7 @@ int orc_wavedec2_array_f32(const float *img, int64_t c, int64_t H, int64_t W, in
     int64_t hs[64], ws[64], ll_h, ll_w, eh, ew;
     int L = orc_geometry_mode(H, W, F, mode, level, hs, ws, &ll_h, &ll_w, &eh, &ew);
     /* (inputs shorter than the filter take the same order of additions: checked against PyWavelets, tests/golden) */
-    float lo[32], hi[32];
+    float lo[MAXF], hi[MAXF];
     for (int j = 0; j < F; j++) { lo[j] = wv->dec_lo_f[j]; hi[j] = wv->dec_hi_f[j]; }
     memset(arr, 0, sizeof(float) * c * eh * ew);
     int64_t offh[64], offw[64];

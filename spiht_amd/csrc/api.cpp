@@ -34,8 +34,9 @@ int spiht_launch_color3(const double *d_in, double *d_out, int B, size_t npix, c
                         hipStream_t st);
 int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st);
 int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, void *t_lo, void *t_hi, void *b_aa, void *b_ad, void *b_da,
-                               void *b_dd, hipStream_t st);
-int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, hipStream_t st);
+                               void *b_dd, const double *d_filt, hipStream_t st);
+int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, const double *d_filt, int per,
+                                hipStream_t st);
 int spiht_launch_idwt_level(const IdwtKArgs *a, int planes, hipStream_t st, TileCtr *tc);
 int spiht_launch_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c, const double *mults,
                              double q, uint32_t *maxabs, hipStream_t st);
@@ -106,6 +107,8 @@ struct spiht_ctx {
     std::vector<PadKey> pads_zeroed;  // arrays whose padding strips this context has zeroed (opt_pads_persist)
     DevBuf l1flags;             // L1Flags words of the fused decode path
     DevBuf exttmp;              // intermediates of the two-pass forward level (extension modes that compute their samples)
+    DevBuf filt;                // the filters of wavelet `filt_wavelet` on the device, for the two-pass levels (any length)
+    int filt_wavelet = -1;
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
     DevBuf recz, lspcnt;
     bool recz_clean = false;
@@ -412,7 +415,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->exttmp, &ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
+    DevBuf *bufs[] = {&ctx->filt, &ctx->exttmp, &ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
                       &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
@@ -1052,6 +1055,30 @@ static int upload_mults(spiht_ctx *ctx, const double *channel_mults, int64_t c, 
 // pixels [planes,H,W] -> quantised packed array [planes,enc_h,enc_w]
 // f32: d_img holds float pixels and the transform runs in single precision, as PyWavelets does for float32 / float16
 // input (every level's input must then be at least as long as the filter: SPIHT_ERR_ARG otherwise)
+// The wavelet's filters on the device for the two-pass levels: dec_lo, dec_hi, rec_lo, rec_hi (F doubles each), then dec_lo,
+// dec_hi as the single-precision transform has them (F floats each).  Uploaded when the wavelet changes.
+static int upload_filters(spiht_ctx *ctx, int wavelet, const double **d_filt) {
+    const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
+    const size_t F = (size_t)wv.F, bytes = 4 * F * 8 + 2 * F * 4;
+    if (ctx->filt_wavelet != wavelet || !ctx->filt.p) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // queued kernels still read the old filters
+        ctx->filt_wavelet = -1;
+        CHK(ensure(ctx, ctx->filt, bytes));
+        std::vector<char> h(bytes);
+        memcpy(h.data(), wv.dec_lo, F * 8);
+        memcpy(h.data() + F * 8, wv.dec_hi, F * 8);
+        memcpy(h.data() + 2 * F * 8, wv.rec_lo, F * 8);
+        memcpy(h.data() + 3 * F * 8, wv.rec_hi, F * 8);
+        memcpy(h.data() + 4 * F * 8, wv.dec_lo_f, F * 4);
+        memcpy(h.data() + 4 * F * 8 + F * 4, wv.dec_hi_f, F * 4);
+        HIPCHK(hipMemcpyAsync(ctx->filt.p, h.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));  // (h is a temporary)
+        ctx->filt_wavelet = wavelet;
+    }
+    *d_filt = (const double *)ctx->filt.p;
+    return SPIHT_OK;
+}
+
 // d_dmsb / cov: the significance pyramid will be built over d_coeffs next (into d_dmsb [planes, enc_h, enc_w]): level 1
 // then writes the D codes it has at hand (dwt.hip: dwt_tile<.., EMIT>) and *cov says which (cov->on = 0: none)
 static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
@@ -1064,7 +1091,12 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
     if (f32 && ig.L == 0) return SPIHT_ERR_ARG;
     bool color = ctx->color_on && c == 3;
     if (color && f32) return SPIHT_ERR_ARG;  // the colour model change is float64 (as colour-science's)
-    if (color && mode >= SPIHT_MODE_SMOOTH && ig.L > 0) {
+    // the plain two-pass level: the modes that compute their extension, periodization, and filters longer than the tiled
+    // kernels take (db11.., sym11.., coif4.., dmey)
+    const bool twopass = mode >= SPIHT_MODE_SMOOTH || wv.F > SPIHT_MAX_TAPS;
+    const double *d_filt = nullptr;
+    if (twopass && ig.L > 0) CHK(upload_filters(ctx, wavelet, &d_filt));
+    if (color && twopass && ig.L > 0) {
         // the two-pass level has no colour form: the colour model change as a pass of its own in front of it
         const size_t npix = (size_t)ig.hs[0] * ig.ws[0];
         CHK(ensure(ctx, ctx->img, (size_t)planes * npix * 8));
@@ -1129,17 +1161,18 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         a.maxabs = d_maxabs;
         a.q = q;
         if (color && l == 1) { a.color = 1; a.col = ctx->col_fwd; }
-        memcpy(a.lo, wv.dec_lo, sizeof(double) * wv.F);
-        memcpy(a.hi, wv.dec_hi, sizeof(double) * wv.F);
-        memcpy(a.lo_f, wv.dec_lo_f, sizeof(float) * wv.F);
-        memcpy(a.hi_f, wv.dec_hi_f, sizeof(float) * wv.F);
+        const int Fc = std::min(wv.F, SPIHT_MAX_TAPS);  // (a longer filter goes by the device copy: two-pass level)
+        memcpy(a.lo, wv.dec_lo, sizeof(double) * Fc);
+        memcpy(a.hi, wv.dec_hi, sizeof(double) * Fc);
+        memcpy(a.lo_f, wv.dec_lo_f, sizeof(float) * Fc);
+        memcpy(a.hi_f, wv.dec_hi_f, sizeof(float) * Fc);
         // (two levels at least: the parents of the level-1 cells are then depth-1 nodes outside the root block)
-        if (l == 1 && ig.L >= 2 && d_dmsb && cov && emit_on && !f32 && !a.color) {
+        if (l == 1 && ig.L >= 2 && d_dmsb && cov && emit_on && !f32 && !a.color && !twopass) {
             a.dmsb = d_dmsb;
             spiht_dwt_d1_cover(&a, cov);
         }
-        if (mode >= SPIHT_MODE_SMOOTH) {
-            // smooth / antisymmetric / antireflect / periodization: two plain passes through an intermediate (dwt.hip:
+        if (twopass) {
+            // smooth / antisymmetric / antireflect / periodization / long filters: two plain passes through an intermediate (dwt.hip:
             // k_dwt_axis_ext), a few planes at a time so that the intermediates stay under a gigabyte; in the pixels' precision
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
             const size_t esz = f32 ? 4 : 8;
@@ -1159,7 +1192,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
                 void *t_lo = base, *t_hi = base + (size_t)np * n_t * esz;
                 char *bb = base + 2 * (size_t)np * n_t * esz;
                 LAUNCHCHK(spiht_launch_dwt_level_ext(&b, np, t_lo, t_hi, bb, bb + (size_t)np * n_b * esz, bb + 2 * (size_t)np * n_b * esz,
-                                                     bb + 3 * (size_t)np * n_b * esz, ctx->stream));
+                                                     bb + 3 * (size_t)np * n_b * esz, d_filt, ctx->stream));
             }
         } else {
             StageTimer t(ctx, l == 1 ? ST_DWT_L1 : ST_DWT_REST);
@@ -1236,11 +1269,13 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
         a.q = q;
         if (color && l == 1) { a.color = 1; a.col = ctx->col_inv; }
         if (l == 1 && !a.first && !a.color) a.flags = d_flags;
-        memcpy(a.lo, wv.rec_lo, sizeof(double) * F);
-        memcpy(a.hi, wv.rec_hi, sizeof(double) * F);
-        if (ig.per) {
-            // periodization: two plain passes through an intermediate (dwt.hip: k_idwt_axis_per), a few planes at a time; the
-            // colour model of the picture as a pass of its own behind level 1
+        memcpy(a.lo, wv.rec_lo, sizeof(double) * std::min(F, SPIHT_MAX_TAPS));
+        memcpy(a.hi, wv.rec_hi, sizeof(double) * std::min(F, SPIHT_MAX_TAPS));
+        if (ig.per || F > SPIHT_MAX_TAPS) {
+            // periodization / a filter longer than the tiled kernels take: two plain passes through an intermediate (dwt.hip:
+            // k_idwt_axis_per), a few planes at a time; the colour model of the picture as a pass of its own behind level 1
+            const double *d_filt;
+            CHK(upload_filters(ctx, wavelet, &d_filt));
             StageTimer t(ctx, l == 1 ? ST_IDWT_L1 : ST_IDWT_REST);
             a.color = 0;
             const size_t per_plane = (size_t)2 * a.band_h * a.out_w * 8;
@@ -1254,7 +1289,7 @@ static int dwt_inverse(spiht_ctx *ctx, const int32_t *d_rec, int planes, int c, 
                 b.rec = a.rec + (size_t)p0 * a.enc_h * a.enc_w;
                 b.out = a.out + (size_t)p0 * a.out_h * a.out_w;
                 double *t_lo = (double *)ctx->exttmp.p, *t_hi = t_lo + (size_t)np * a.band_h * a.out_w;
-                LAUNCHCHK(spiht_launch_idwt_level_per(&b, np, t_lo, t_hi, ctx->stream));
+                LAUNCHCHK(spiht_launch_idwt_level_per(&b, np, t_lo, t_hi, d_filt, ig.per ? 1 : 0, ctx->stream));
             }
             if (color && l == 1)
                 LAUNCHCHK(spiht_launch_color3(a.out, a.out, planes / 3, (size_t)a.out_h * a.out_w, ctx->col_inv.A, ctx->col_inv.M,

@@ -839,6 +839,10 @@ __device__ __forceinline__ T ext_value(const T *x, int N, size_t sx, int i, int 
         return x[(size_t)(m < N ? m : N - 1) * sx];
     }
     if (i >= 0 && i < N) return x[(size_t)i * sx];
+    if (mode < 5) {  // the index maps (filters longer than the tiled kernels take come through here too)
+        const int m = ext_index(i, N, mode);
+        return m < 0 ? (T)0 : x[(size_t)m * sx];
+    }
     if (mode == 5) {  // smooth: the straight line through the two samples at the edge
         if (N < 2) return x[0];
         if (i < 0) return x[0] + (T)(-i) * (x[0] - x[sx]);
@@ -880,8 +884,8 @@ struct DwtAxisArgs {
     size_t so, sol, plane_out;   // output alike
     const void *in;
     void *lo, *hi;
-    double flo[SPIHT_MAX_TAPS], fhi[SPIHT_MAX_TAPS];
-    float flo_f[SPIHT_MAX_TAPS], fhi_f[SPIHT_MAX_TAPS];
+    const double *flo, *fhi;     // device: dec_lo, dec_hi (any length: the whole PyWavelets table goes through this path)
+    const float *flo_f, *fhi_f;  // ... as the single-precision transform has them
 };
 template <typename T>
 __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
@@ -896,7 +900,7 @@ __global__ __launch_bounds__(256) void k_dwt_axis_ext(DwtAxisArgs a) {
     else { o = (int)(r / a.n_lines); line = (int)(r - (size_t)o * a.n_lines); }
     const T *x = reinterpret_cast<const T *>(a.in) + (size_t)plane * a.plane_in + (size_t)line * a.sl;
     const int i = 2 * o + a.i0;
-    const int jb = (i >= a.N && a.mode != 5) ? i - a.N : -1;
+    const int jb = (i >= a.N && a.mode != 5 && a.mode != 4) ? i - a.N : -1;  // (smooth and constant: ascending throughout)
     T sa = 0, sd = 0;
     for (int s2 = 0; s2 < a.F; s2++) {
         const int j = s2 <= jb ? jb - s2 : s2;
@@ -954,13 +958,16 @@ __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
     }
 }
 // tmp: 6 arrays of planes*out_h*in_w (2) and planes*out_h*out_w (4) elements (float when a->f32), carved by the caller
+// d_filt: the wavelet's filters on the device -- dec_lo, dec_hi, rec_lo, rec_hi (F doubles each), then dec_lo, dec_hi as the
+// single-precision transform has them (F floats each)
 extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, void *t_lo, void *t_hi, void *b_aa, void *b_ad,
-                                          void *b_da, void *b_dd, hipStream_t st) {
+                                          void *b_da, void *b_dd, const double *d_filt, hipStream_t st) {
     DwtAxisArgs x;
     memset(&x, 0, sizeof(x));
     x.F = a->F; x.mode = a->mode; x.planes = planes;
     x.i0 = a->mode == 8 ? a->F / 2 : 1;
-    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; x.flo_f[j] = a->lo_f[j]; x.fhi_f[j] = a->hi_f[j]; }
+    x.flo = d_filt; x.fhi = d_filt + a->F;
+    x.flo_f = reinterpret_cast<const float *>(d_filt + 4 * (size_t)a->F); x.fhi_f = x.flo_f + a->F;
     const bool f32 = a->f32 != 0;
     auto axis = [&](size_t n) {
         if (f32) hipLaunchKernelGGL(k_dwt_axis_ext<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x);
@@ -1001,6 +1008,9 @@ extern "C" int spiht_launch_dwt_level_ext(const DwtKArgs *a, int planes, void *t
 // through an intermediate: the plain form of a mode nobody's headline runs on.
 struct IdwtPerArgs {
     int32_t F, L, n_lines, planes;     // L coefficients per line, n_lines lines
+    int32_t per, n_out;                // periodization (2 L samples) or the plain synthesis (2 L - F + 2 samples: filters longer than
+                                       // the tiled kernels take)
+    const double *flo_d, *fhi_d;       // device: rec_lo, rec_hi
     size_t si, so;                     // element stride along the axis: inputs, output
     size_t sla, sld, slo;              // stride between lines: approximation input, detail input, output
     size_t plane_a, plane_d, plane_out;
@@ -1010,51 +1020,69 @@ struct IdwtPerArgs {
     const double *mults;
     double q;
     double *out;
-    double flo[SPIHT_MAX_TAPS], fhi[SPIHT_MAX_TAPS];
 };
 __global__ __launch_bounds__(256) void k_idwt_axis_per(IdwtPerArgs a) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t per_plane = (size_t)2 * a.L * a.n_lines;
+    const size_t per_plane = (size_t)a.n_out * a.n_lines;
     if (t >= per_plane * (size_t)a.planes) return;
     const int plane = (int)(t / per_plane);
     const size_t r = t - (size_t)plane * per_plane;
     int n, line;  // consecutive threads along the contiguous direction of the output
-    if (a.so == 1) { line = (int)(r / (2 * (size_t)a.L)); n = (int)(r - (size_t)line * 2 * a.L); }
+    if (a.so == 1) { line = (int)(r / (size_t)a.n_out); n = (int)(r - (size_t)line * a.n_out); }
     else { n = (int)(r / a.n_lines); line = (int)(r - (size_t)n * a.n_lines); }
-    const int HF = a.F / 2, s0 = HF - 1;
-    const int p = (n + s0) & 1, i = (n + s0 - p) / 2;
-    int jb = i >= a.L ? i - a.L : -1;
-    if (n == 0 && (HF & 1) == 0) jb = a.F / 4 - 1;
+    const int HF = a.F / 2;
     const bool has_m = a.has_m != 0;
     const double mk = has_m ? a.mults[plane % a.c] : 1.0;
     const size_t ba = (size_t)plane * a.plane_a + (size_t)line * a.sla, bd = (size_t)plane * a.plane_d + (size_t)line * a.sld;
-    double acc = 0.0;
+    auto va = [&](int k) -> double { return a.a_is_q ? dequant(a.qa[ba + (size_t)k * a.si], mk, a.q, has_m) : a.ca[ba + (size_t)k * a.si]; };
+    auto vd = [&](int k) -> double { return a.d_is_q ? dequant(a.qd[bd + (size_t)k * a.si], mk, a.q, has_m) : a.cd[bd + (size_t)k * a.si]; };
+    double res;
+    if (a.per) {
+        const int s0 = HF - 1, p = (n + s0) & 1, i = (n + s0 - p) / 2;
+        int jb = i >= a.L ? i - a.L : -1;
+        if (n == 0 && (HF & 1) == 0) jb = a.F / 4 - 1;
+        double acc = 0.0;
 #pragma unroll 1
-    for (int pass = 0; pass < 2; pass++) {
-        const double *f = pass ? a.fhi : a.flo;
-        for (int s2 = 0; s2 < HF; s2++) {
-            const int j = s2 <= jb ? jb - s2 : s2;
-            int k = (i - j) % a.L;
-            if (k < 0) k += a.L;
-            double v;
-            if (pass == 0) v = a.a_is_q ? dequant(a.qa[ba + (size_t)k * a.si], mk, a.q, has_m) : a.ca[ba + (size_t)k * a.si];
-            else v = a.d_is_q ? dequant(a.qd[bd + (size_t)k * a.si], mk, a.q, has_m) : a.cd[bd + (size_t)k * a.si];
-            acc += f[2 * j + p] * v;
+        for (int pass = 0; pass < 2; pass++) {
+            const double *f = pass ? a.fhi_d : a.flo_d;
+            for (int s2 = 0; s2 < HF; s2++) {
+                const int j = s2 <= jb ? jb - s2 : s2;
+                int k = (i - j) % a.L;
+                if (k < 0) k += a.L;
+                acc += f[2 * j + p] * (pass ? vd(k) : va(k));
+            }
         }
+        res = acc;
+    } else {
+        // upsampling_convolution_valid_sf: sample n = 2 (i - (F/2 - 1)) + p; the approximation's sum and the detail's sum kept
+        // apart, each over j ascending (tap 2j + p against coefficient i - j, those inside the band), then added
+        const int p = n & 1, i = n / 2 + HF - 1;
+        double sa = 0.0, sd = 0.0;
+        for (int j = 0; j < HF; j++) {
+            const int k = i - j;
+            if (k < 0 || k >= a.L) continue;
+            sa += a.flo_d[2 * j + p] * va(k);
+            sd += a.fhi_d[2 * j + p] * vd(k);
+        }
+        res = (0.0 + sa) + sd;
     }
-    a.out[(size_t)plane * a.plane_out + (size_t)line * a.slo + (size_t)n * a.so] = acc;
+    a.out[(size_t)plane * a.plane_out + (size_t)line * a.slo + (size_t)n * a.so] = res;
 }
 // t_lo, t_hi: planes * band_h * out_w doubles each (out_w = 2 band_w, out_h = 2 band_h)
-extern "C" int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, hipStream_t st) {
+// per: periodization (a->out_h / out_w = 2 x band) or the plain synthesis for a filter of any length (2 x band - F + 2);
+// d_filt: the wavelet's filters on the device (see spiht_launch_dwt_level_ext)
+extern "C" int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, double *t_lo, double *t_hi, const double *d_filt, int per,
+                                           hipStream_t st) {
     IdwtPerArgs x;
     memset(&x, 0, sizeof(x));
     x.F = a->F; x.planes = planes; x.c = a->c; x.has_m = a->mults != nullptr; x.mults = a->mults; x.q = a->q;
-    for (int j = 0; j < a->F; j++) { x.flo[j] = a->lo[j]; x.fhi[j] = a->hi[j]; }
+    x.per = per;
+    x.flo_d = d_filt + 2 * (size_t)a->F; x.fhi_d = d_filt + 3 * (size_t)a->F;
     const size_t enc_plane = (size_t)a->enc_h * a->enc_w;
     // axis -1 (PyWavelets' idwtn takes the last axis first): band_h lines of band_w coefficients -> out_w samples
-    x.L = a->band_w; x.n_lines = a->band_h;
+    x.L = a->band_w; x.n_lines = a->band_h; x.n_out = a->out_w;
     x.si = 1; x.so = 1; x.slo = (size_t)a->out_w; x.plane_out = (size_t)a->band_h * a->out_w;
-    const size_t n1 = (size_t)planes * 2 * x.L * x.n_lines;
+    const size_t n1 = (size_t)planes * x.n_out * x.n_lines;
     // (aa, ad) -> low rows: the approximation comes out of the packed array (coarsest level) or from the level before, whose
     // array may be one sample longer than the band in either direction (waverec2 drops it)
     if (a->first) { x.a_is_q = 1; x.qa = a->rec; x.plane_a = enc_plane; x.sla = (size_t)a->enc_w; }
@@ -1068,12 +1096,12 @@ extern "C" int spiht_launch_idwt_level_per(const IdwtKArgs *a, int planes, doubl
     x.out = t_hi;
     hipLaunchKernelGGL(k_idwt_axis_per, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, x);
     // axis -2: out_w lines (columns) of band_h coefficients -> out_h samples
-    x.L = a->band_h; x.n_lines = a->out_w;
+    x.L = a->band_h; x.n_lines = a->out_w; x.n_out = a->out_h;
     x.si = (size_t)a->out_w; x.sla = 1; x.sld = 1; x.plane_a = x.plane_d = (size_t)a->band_h * a->out_w;
     x.so = (size_t)a->out_w; x.slo = 1; x.plane_out = (size_t)a->out_h * a->out_w;
     x.a_is_q = 0; x.d_is_q = 0; x.ca = t_lo; x.cd = t_hi;
     x.out = a->out;
-    const size_t n2 = (size_t)planes * 2 * x.L * x.n_lines;
+    const size_t n2 = (size_t)planes * x.n_out * x.n_lines;
     hipLaunchKernelGGL(k_idwt_axis_per, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, st, x);
     return (int)hipGetLastError();
 }

@@ -67,9 +67,8 @@ def _wavelet_mode_ids(spiht_settings):
     wid = L.spiht_wavelet_id(str(spiht_settings.wavelet).encode())
     if wid < 0:
         # pywt.Wavelet(name) raises this ValueError for a name it does not know (spiht_wrapper.py:163 reaches it through
-        # wavedec2); the wavelets PyWavelets has with more than 20 taps (db11.., sym11.., coif4.., dmey) are refused too
-        raise ValueError("Unknown wavelet name '%s', check wavelist() for the list of available builtin wavelets "
-                         "(supported here: every discrete PyWavelets wavelet with at most 20 taps)." % spiht_settings.wavelet)
+        # wavedec2); all 106 discrete wavelets of PyWavelets are known here (csrc/wavelets.h)
+        raise ValueError("Unknown wavelet name '%s', check wavelist() for the list of available builtin wavelets." % spiht_settings.wavelet)
     mid = L.spiht_mode_id(str(spiht_settings.mode).encode())
     if mid < 0:
         # pywt.Modes.from_object raises ValueError("Unknown mode name '...'.") (reached from spiht_wrapper.py:163)

@@ -459,6 +459,66 @@ def part_short():
     print("wrote short_pywt.npz:", i, "cases; pywt", pywt.__version__)
 
 
+def thin_out(qa, seed):
+    """a decoder's partial picture of the int32 array: about half the coefficients lose their two low bits"""
+    rng = np.random.default_rng(seed)
+    return (qa - (qa % 4) * (rng.random(qa.shape) < 0.5)).astype(np.int32)
+
+
+def part_long():
+    """the 53 discrete wavelets of PyWavelets with MORE than 20 taps (db11-38, sym11-20, coif4-17, dmey: up to 102 taps),
+    which the reference takes like any other name (spiht_wrapper.py:163, :276): pictures longer and shorter than the filter,
+    one or two levels, all nine extension modes in turn, float64 -- and float32 pixels for the coiflets (whose
+    single-precision filters PyWavelets builds from a float table) and a few others.  SHA-256 of the packed array, of the
+    int32 array and of the picture waverec2 gives back from thin_out(int32 array), for every case; the arrays themselves for
+    every fifth -> long_pywt.npz"""
+    import hashlib
+    import pywt
+    names = [n for n in pywt.wavelist(kind="discrete") if pywt.Wavelet(n).dec_len > 20]
+    modes = ["reflect", "symmetric", "periodic", "zero", "constant", "smooth", "antisymmetric", "antireflect", "periodization"]
+    rng = np.random.default_rng(2024)
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    out = {"pywt_version": np.array(pywt.__version__), "names": np.array(names),
+           "dec_len": np.array([pywt.Wavelet(n).dec_len for n in names])}
+    for n in names:
+        out["fb_" + n] = np.array(pywt.Wavelet(n).filter_bank, dtype=np.float64)
+    i = 0
+    for k, n in enumerate(names):
+        F = pywt.Wavelet(n).dec_len
+        for dt in (np.float64, np.float32):
+            if dt == np.float32 and not (n.startswith("coif") or n in ("db11", "db38", "sym20", "dmey")):
+                continue
+            kind = (k + (dt == np.float32)) % 3  # both sides longer than the filter / one shorter / both shorter
+            H = int(rng.integers(F + 1, F + 24)) if kind == 0 else int(rng.integers(3, F))
+            W = int(rng.integers(F + 1, F + 40)) if kind <= 1 else int(rng.integers(3, F))
+            if k % 2:
+                H, W = W, H
+            lv, c, q = 1 + k % 2, 1 + (k % 4 == 0), [50.0, 255.0, 10.0][k % 3]
+            mode = modes[(k + 4 * (dt == np.float32)) % len(modes)]
+            img = (blocky_image(900 + i, c, H, W) if k % 2 else synth_image(900 + i, c, H, W)).astype(dt)
+            co = pywt.wavedec2(img, wavelet=n, level=lv, mode=mode)
+            arr, slices = pywt.coeffs_to_array(co, axes=(-2, -1))
+            assert arr.dtype == dt
+            qa = np.ascontiguousarray((arr * dt(q)).astype(np.int32))
+            p = "c%d_" % i
+            out[p + "meta"] = np.array([900 + i, c, H, W, lv, k % 2, int(dt == np.float32)])
+            out[p + "wavelet"], out[p + "mode"], out[p + "q"] = np.array(n), np.array(mode), np.array(q)
+            out[p + "shape"] = np.array(arr.shape)
+            out[p + "sha_arr"], out[p + "sha_quant"] = sha(arr), sha(qa)
+            if dt == np.float64:
+                rec = thin_out(qa, 900 + i)
+                back = pywt.waverec2(pywt.array_to_coeffs(rec / q, slices, output_format="wavedec2"), mode=mode, wavelet=n)
+                out[p + "back_shape"], out[p + "sha_rec_img"] = np.array(back.shape), sha(back)
+            if i % 5 == 0:
+                out[p + "arr"] = arr
+                if dt == np.float64:
+                    out[p + "rec_img"] = back
+            i += 1
+    out["ncases"] = np.array(i)
+    np.savez_compressed(os.path.join(HERE, "long_pywt.npz"), **out)
+    print("wrote long_pywt.npz:", i, "cases; pywt", pywt.__version__)
+
+
 if __name__ == "__main__":
     {"loops": part_loops, "wrapper": part_wrapper, "bench": part_bench, "wrapper32": part_wrapper32,
-     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes, "modes32": part_modes32, "short": part_short}[sys.argv[1]]()
+     "blocky": part_blocky, "wavelets": part_wavelets, "modes": part_modes, "modes32": part_modes32, "short": part_short, "long": part_long}[sys.argv[1]]()

@@ -435,7 +435,7 @@ def test_every_wavelet_up_to_20_taps(oracle):
             assert np.array_equal(back[b], ref), (wv, F)
     import spiht_amd
     with pytest.raises(ValueError):
-        spiht_amd.encode_image(np.zeros((1, 64, 64)), spiht_amd.SpihtSettings(wavelet="db11"))   # 22 taps: refused
+        spiht_amd.encode_image(np.zeros((1, 64, 64)), spiht_amd.SpihtSettings(wavelet="db39"))   # (PyWavelets stops at db38)
     with pytest.raises(ValueError):
         spiht_amd.encode_image(np.zeros((1, 64, 64)), spiht_amd.SpihtSettings(wavelet="nonsense"))
 
@@ -558,3 +558,60 @@ def test_single_precision_computed_modes_and_coiflets(oracle):
         enc = spiht_amd.encode_image(img, spiht_amd.SpihtSettings(wavelet=wv, mode=mode), level=2, max_bits=40000)
         ref_bytes, ref_n, _ = oracle.encode_image(img, wv, mode, 2, 50.0, None, 40000)
         assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n, (wv, mode)
+
+
+def test_wavelets_above_20_taps(oracle):
+    """db11-38, sym11-20, coif4-17, dmey (22 to 102 taps; the reference takes any PyWavelets name, spiht_wrapper.py:163, :276)
+    go through the two-pass levels with the filters read from device memory (dwt.hip: k_dwt_axis_ext / k_idwt_axis_per):
+    the int32 array and the picture back against PyWavelets 1.1.1 (tests/golden/long_pywt.npz), all nine modes, float64 and
+    float32; then pictures larger than a tile with channel scales and a colour model against the oracle, the coder included."""
+    import spiht_amd
+    from golden.make_golden import thin_out
+    from test_oracle import long_cases, sha256_of
+    n = 0
+    for cs in long_cases():
+        tag = (cs["wavelet"], cs["mode"], cs["level"], cs["img"].shape, cs["img"].dtype)
+        if cs["f32"]:
+            got = _gpu_dwt_f32(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"])[0]
+        else:
+            got = _gpu_dwt(cs["img"][None], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+        assert got.shape == cs["shape"], tag
+        assert np.array_equal(sha256_of(got), cs["sha_quant"]), tag
+        if not cs["f32"]:
+            back = _gpu_idwt(thin_out(got, cs["seed"])[None], cs["H"], cs["W"], cs["wavelet"], cs["mode"], cs["level"], cs["q"], None)[0]
+            assert back.shape == tuple(cs["back_shape"]) and np.array_equal(sha256_of(back), cs["sha_rec_img"]), tag
+        n += 1
+    assert n == 71
+    imgs = np.stack([synth_image(70 + b, 3, 211, 318) for b in range(3)])
+    for wv, mode, lv in (("db20", "reflect", 3), ("coif8", "periodization", 2), ("dmey", "symmetric", None), ("sym13", "antireflect", 2),
+                         ("db38", "periodic", 1), ("coif17", "zero", 2)):
+        got = _gpu_dwt(imgs, wv, mode, lv, 50.0, [1.0, 0.5, 2.0])
+        for b in range(3):
+            arr, _ = oracle.wavedec2_array(imgs[b], wv, mode, lv)
+            assert np.array_equal(got[b], oracle.quantize(arr, 50.0, [1.0, 0.5, 2.0])), (wv, mode)
+        rec = np.stack([thin_out(got[b], b) for b in range(3)])
+        back = _gpu_idwt(rec, 211, 318, wv, mode, lv, 50.0, [1.0, 0.5, 2.0])
+        for b in range(3):
+            ref = oracle.waverec2_array(oracle.dequantize(rec[b], 50.0, [1.0, 0.5, 2.0]), 211, 318, wv, lv, mode)
+            assert np.array_equal(back[b].view(np.uint64), ref.view(np.uint64)), (wv, mode)
+        s = spiht_amd.SpihtSettings(wavelet=wv, mode=mode)
+        enc = spiht_amd.encode_image(imgs[0], s, lv, 30000)
+        ref_bytes, ref_n, _ = oracle.encode_image(imgs[0], wv, mode, lv, 50.0, None, 30000)
+        assert enc.encoded_bytes == ref_bytes and enc.max_n == ref_n, (wv, mode)
+        dec = spiht_amd.decode_image(enc, s)
+        assert np.array_equal(dec, oracle.decode_image(ref_bytes, ref_n, 3, 211, 318, wv, enc.level, 50.0, None, mode=mode)), (wv, mode)
+    # a colour model around a long filter: the change runs as a pass of its own on either side of the two-pass levels
+    sc = spiht_amd.SpihtSettings(wavelet="sym16", color_model="IPT", quantization_scale=1.0, per_channel_quant_scales=[50.0, 15.0, 15.0])
+    e2 = spiht_amd.encode_image(imgs[1], sc, 3, 200000)
+    from spiht_amd import _lib, color_models
+    from spiht_amd.batch import DeviceArray
+    ctx = _lib.default_context()
+    d = DeviceArray(ctx, imgs[1].shape, np.float64)
+    d.upload(imgs[1])
+    color_models.device_convert(ctx, d.ptr, 1, 211 * 318, "RGB", "IPT")   # the same kernel, as a call of its own
+    ctx.synchronize()
+    ref_bytes, ref_n, _ = oracle.encode_image(d.download(), "sym16", "reflect", 3, 1.0, [50.0, 15.0, 15.0], 200000)
+    d.free()
+    assert e2.encoded_bytes == ref_bytes and e2.max_n == ref_n
+    d2 = spiht_amd.decode_image(e2, sc)
+    assert np.abs(d2[:, :211, :318] - imgs[1]).mean() < 0.05

@@ -455,3 +455,64 @@ def test_single_precision_computed_modes_and_coiflets_match_pywt(oracle):
         assert np.array_equal(oracle.quantize_f32(arr, 50.0), cs["quant"])
         n += 1
     assert n == 27
+
+
+def long_cases():
+    """cases of tests/golden/long_pywt.npz (make_golden.py: part_long): SHA-256 of what PyWavelets 1.1.1 computed, the
+    arrays themselves for every fifth case"""
+    import hashlib
+    from golden.make_golden import blocky_image, synth_image as gold_synth
+    z = np.load(os.path.join(GOLD, "long_pywt.npz"))
+    for i in range(int(z["ncases"])):
+        p = "c%d_" % i
+        seed, c, H, W, lv, blocky, f32 = [int(v) for v in z[p + "meta"]]
+        img = (blocky_image(seed, c, H, W) if blocky else gold_synth(seed, c, H, W)).astype(np.float32 if f32 else np.float64)
+        d = dict(i=i, seed=seed, img=img, c=c, H=H, W=W, level=lv, f32=bool(f32), wavelet=str(z[p + "wavelet"]), mode=str(z[p + "mode"]),
+                 q=float(z[p + "q"]), shape=tuple(int(v) for v in z[p + "shape"]))
+        for k in ("sha_arr", "sha_quant", "sha_rec_img", "arr", "rec_img", "back_shape"):
+            d[k] = z[p + k] if p + k in z.files else None
+        yield d
+
+
+def sha256_of(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_every_wavelet_above_20_taps_matches_pywt(oracle):
+    """db11-38, sym11-20, coif4-17 and dmey -- filters of 22 to 102 taps, which the reference takes like any other name
+    (spiht_wrapper.py:163, :276): filter banks, the packed coefficient array in every bit (float64, and float32 for the
+    coiflets' own single-precision filters), the int32 array, and the picture waverec2 gives back from a thinned-out copy of
+    it, all nine extension modes in turn, against PyWavelets 1.1.1 (tests/golden/long_pywt.npz)."""
+    from golden.make_golden import thin_out
+    z = np.load(os.path.join(GOLD, "long_pywt.npz"))
+    names = [str(n) for n in z["names"]]
+    assert len(names) == 53 and int(max(z["dec_len"])) == 102
+    for n, F in zip(names, z["dec_len"]):
+        fb = oracle.wavelet_filters(n)
+        assert len(fb[0]) == int(F) and np.array_equal(np.array(fb), z["fb_" + n]), n
+    seen, modes, n32 = set(), set(), 0
+    for cs in long_cases():
+        tag = (cs["wavelet"], cs["mode"], cs["level"], cs["img"].shape, cs["img"].dtype)
+        if cs["f32"]:
+            arr, _ = oracle.wavedec2_array_f32(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
+            qa = oracle.quantize_f32(arr, cs["q"])
+            n32 += 1
+        else:
+            arr, _ = oracle.wavedec2_array(cs["img"], cs["wavelet"], cs["mode"], cs["level"])
+            qa = oracle.quantize(arr, cs["q"])
+        assert arr.shape == cs["shape"], tag
+        if cs["arr"] is not None:
+            assert np.array_equal(arr.view(np.uint8), cs["arr"].view(np.uint8)), tag
+        assert np.array_equal(sha256_of(arr), cs["sha_arr"]), tag
+        assert np.array_equal(sha256_of(qa), cs["sha_quant"]), tag
+        if not cs["f32"]:
+            rec = thin_out(qa, cs["seed"])
+            back = oracle.waverec2_array(oracle.dequantize(rec, cs["q"]), cs["H"], cs["W"], cs["wavelet"], cs["level"], cs["mode"])
+            assert back.shape == tuple(cs["back_shape"]), tag
+            if cs["rec_img"] is not None:
+                assert np.array_equal(back.view(np.uint64), cs["rec_img"].view(np.uint64)), tag
+            assert np.array_equal(sha256_of(back), cs["sha_rec_img"]), tag
+        seen.add(cs["wavelet"])
+        modes.add(cs["mode"])
+    assert seen == set(names) and len(modes) == 9 and n32 == 18
