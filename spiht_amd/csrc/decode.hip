@@ -141,6 +141,7 @@ struct DecShared {
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
     uint32_t wdone[DEC_NWK];    // items completed per worker
     uint32_t bad;
+    uint32_t ndup;              // LSP entries of duplicated cells met by the final scatter (resolve_dups walks only those)
     // results of a phase, written by the sequencer before the closing barrier
     uint32_t r_P, r_done, r_lsp, r_lip;
 };
@@ -480,37 +481,44 @@ __device__ __forceinline__ uint32_t ld_l2(const uint32_t *p) {  // bypasses the 
 template <uint32_t IDXM>
 __device__ __forceinline__ void resolve_dups(const Geom &g, int32_t *out, const uint32_t *lsp_idx, const int32_t *lsp_val,
                                              uint32_t lsp_len, uint32_t *mailA, uint32_t *mailB, uint32_t ref_plane,
-                                             uint32_t ref_count) {
+                                             uint32_t ref_count, const uint32_t *dlist, uint32_t ndup) {
+    // dlist[0, ndup): the LSP positions whose cell is a duplicated one, in no particular order, as the final scatter met
+    // them (a small part of the list: five walks over ALL of it took longer than the scatter itself).  dlist == nullptr
+    // (the list did not fit its buffer: tiny root blocks at full rate): every LSP position is tested instead.
     constexpr uint32_t NT = DEC_NW * 64, OWNER = 0xFFFFFFFFu;
     uint32_t *cells = reinterpret_cast<uint32_t *>(out);
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 0: elect
-        const uint32_t idx = lsp_idx[t] & IDXM;
-        if (!dup_cell(g, idx)) continue;
+    auto each = [&](auto f) {
+        if (dlist) {
+            for (uint32_t q = threadIdx.x; q < ndup; q += NT) {
+                const uint32_t t = dlist[q];
+                f(t, lsp_idx[t] & IDXM);
+            }
+        } else {
+            for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {
+                const uint32_t idx = lsp_idx[t] & IDXM;
+                if (dup_cell(g, idx)) f(t, idx);
+            }
+        }
+    };
+    each([&](uint32_t t, uint32_t idx) {  // round 0: elect
         mailA[t] = 0;
         mailB[t] = 0;
         atomicMax(&cells[idx], t + 1u);
-    }
+    });
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 1: the newest of the others
-        const uint32_t idx = lsp_idx[t] & IDXM;
-        if (!dup_cell(g, idx)) continue;
+    each([&](uint32_t t, uint32_t idx) {  // round 1: the newest of the others
         const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
         if (t1 != t && t1 < lsp_len) atomicMax(&mailA[t1], t + 1u);  // (t1 >= lsp_len: the caller's array was not zero --
                                                                       //  its output is wrong then, but nothing may fault)
-    }
+    });
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 2: a third entry (corner cells)
-        const uint32_t idx = lsp_idx[t] & IDXM;
-        if (!dup_cell(g, idx)) continue;
+    each([&](uint32_t t, uint32_t idx) {  // round 2: a third entry (corner cells)
         const uint32_t t1 = ld_l2(&cells[idx]) - 1u;
         if (t1 != t && t1 < lsp_len && ld_l2(&mailA[t1]) != t + 1u) atomicMax(&mailB[t1], t + 1u);
-    }
+    });
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 3: the owner replays
-        const uint32_t idx = lsp_idx[t] & IDXM;
-        if (!dup_cell(g, idx)) continue;
-        if (ld_l2(&cells[idx]) - 1u != t) continue;
+    each([&](uint32_t t, uint32_t idx) {  // round 3: the owner replays
+        if (ld_l2(&cells[idx]) - 1u != t) return;
         uint32_t m2 = ld_l2(&mailA[t]), m3 = ld_l2(&mailB[t]);
         if (m2 > lsp_len) m2 = 0;  // (as above: only a dirty array can leave such a word)
         if (m3 > lsp_len) m3 = 0;
@@ -522,13 +530,11 @@ __device__ __forceinline__ void resolve_dups(const Geom &g, int32_t *out, const 
         ts[cnt] = t; vs[cnt] = lsp_val[t]; cnt++;
         mailA[t] = (uint32_t)replay_dup(ts, vs, cnt, ref_plane, ref_count);
         mailB[t] = OWNER;
-    }
+    });
     __syncthreads();  // every entry has read the election result: the cells can take their values
-    for (uint32_t t = threadIdx.x; t < lsp_len; t += NT) {  // round 4 (an owner reads back its own two stores)
-        const uint32_t idx = lsp_idx[t] & IDXM;
-        if (!dup_cell(g, idx)) continue;
+    each([&](uint32_t t, uint32_t idx) {  // round 4 (an owner reads back its own two stores)
         if (mailB[t] == OWNER) out[idx] = (int32_t)mailA[t];
-    }
+    });
 }
 
 // ---- per-lane work of one LIP window (worker) ----
@@ -869,7 +875,7 @@ void k_decode(DecArgs a) {
 
         __syncthreads();  // previous image fully finished with the shared state
         if (threadIdx.x == 0) {
-            sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.bad = 0;
+            sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.bad = 0; sh.ndup = 0;
             sh.pprog = 0; sh.sprog = 0;
             for (int w = 0; w < DEC_NWK; w++) sh.wdone[w] = 0;
             for (int r = 0; r < DEC_RING; r++) { sh.chain[r].seq = 0; sh.ring[r].ready = 0; }
@@ -907,7 +913,9 @@ void k_decode(DecArgs a) {
 
         // the sequencer is the serial chain of the whole image: when other kernels (or other images' workers) share
         // its SIMD it must not queue for issue slots behind them
+#ifndef DEC_SEQ_NOPRIO
         if (wave == 0) __builtin_amdgcn_s_setprio(3);
+#endif
         bool done = bad;
         for (; !done; --n) {
             const uint32_t lsp_len0 = lsp_len;
@@ -1312,12 +1320,20 @@ void k_decode(DecArgs a) {
             };
             const bool mark = !META && a.fl.p != nullptr;
             const uint32_t plane0 = (uint32_t)b * (uint32_t)g.c;
-            auto st = [&](const int32_t(&v)[U], const uint32_t(&ix)[U]) {
+            // LSP positions of duplicated cells go to a list of their own (the LIS buffers are free by now)
+            auto st = [&](uint32_t t0, const int32_t(&v)[U], const uint32_t(&ix)[U]) {
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
-                    if (v[u] && !(dups && dup_cell(g, ix[u] & IDXM))) out[ix[u] & IDXM] = v[u];
-                    // (every entry with a value, those of duplicated cells included: a set word only means "read")
-                    if (mark && v[u]) l1_mark(g, a.fl, plane0, ix[u] & IDXM);
+                    if (v[u]) {
+                        if (dups && dup_cell(g, ix[u] & IDXM)) {
+                            const uint32_t q = atomicAdd(&sh.ndup, 1u);
+                            if (q < a.caps.lis) q0[q] = t0 + u * STR;
+                        } else {
+                            out[ix[u] & IDXM] = v[u];
+                        }
+                        // (every entry with a value, those of duplicated cells included: a set word only means "read")
+                        if (mark) l1_mark(g, a.fl, plane0, ix[u] & IDXM);
+                    }
                 }
             };
             if (t_end > 0) {
@@ -1325,13 +1341,17 @@ void k_decode(DecArgs a) {
                 ld(t0, va, ia);
                 for (; t0 < t_end; t0 += 2 * STR * U) {
                     ld(t0 + STR * U, vb, ib);
-                    st(va, ia);
+                    st(t0, va, ia);
                     ld(t0 + 2 * STR * U, va, ia);
-                    st(vb, ib);
+                    st(t0 + STR * U, vb, ib);
                 }
             }
         }
-        if (dups) resolve_dups<IDXM>(g, out, lsp_idx, lsp_val, lsp_len, lipA, lipB, ref_plane, ref_count);
+        if (dups) {
+            __syncthreads();  // the list and its length are complete
+            const uint32_t nd = sh.ndup;
+            resolve_dups<IDXM>(g, out, lsp_idx, lsp_val, lsp_len, lipA, lipB, ref_plane, ref_count, nd <= a.caps.lis ? q0 : nullptr, nd);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             if (a.lsp_count) a.lsp_count[slot] = lsp_len;

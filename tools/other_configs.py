@@ -67,6 +67,10 @@ def run(name, B, c, H, W, settings, level, max_bits, distinct, reps=5, cpu_image
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "single":  # the two single-image configurations alone (for a kernel trace)
+        run("cfg2  1 x 1920x1080 RGB, bior2.2 L7, 0.5 bpp", 1, 3, 1080, 1920, SpihtSettings(), 7, int(1080 * 1920 * 0.5), 1)
+        run("cfg5  1 x 4096x4096 RGB, bior6.8 L9, 1.000 bpp", 1, 3, 4096, 4096, SpihtSettings(wavelet="bior6.8"), 9, 4096 * 4096, 1, reps=3)
+        sys.exit(0)
     s3 = SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
     run("cfg3  256 x 1024x1024 RGB, IPT, 0.1 bpp", 256, 3, 1024, 1024, s3, None, int(1024 * 1024 * 0.1), 8, cpu_images=4)
     s5 = SpihtSettings(wavelet="bior6.8")
