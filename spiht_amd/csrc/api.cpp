@@ -21,6 +21,7 @@ int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dm
                          hipStream_t st);
 void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
+int spiht_launch_encode_wide(const EncArgs *a, const WideArgs *w, int groups, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
 int spiht_launch_decode_w8(const DecArgs *a, hipStream_t st);  // the 8-wavefront build of decode.hip
 int spiht_launch_unscatter(const DecArgs *a, hipStream_t st);
@@ -107,6 +108,9 @@ struct spiht_ctx {
     std::vector<PadKey> pads_zeroed;  // arrays whose padding strips this context has zeroed (opt_pads_persist)
     DevBuf l1flags;             // L1Flags words of the fused decode path
     DevBuf exttmp;              // intermediates of the two-pass forward level (extension modes that compute their samples)
+    DevBuf widebuf;             // control blocks and scan descriptors of the several-CUs-per-image encoder (encode_wide.hip)
+    int opt_wide_g = 0;         // workgroups per image of that encoder (0: by the size of the image)
+    int opt_wide_encode = 1;    // few images per call: one image on several CUs (2: whatever the image's size -- tests)
     DevBuf filt;                // the filters of wavelet `filt_wavelet` on the device, for the two-pass levels (any length)
     int filt_wavelet = -1;
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
@@ -318,10 +322,10 @@ static void list_caps(const Geom &g, uint64_t max_bits, ListCaps *caps, uint64_t
     uint64_t lip = nodes, lsp = nodes, lis = parents + 4 * roots;  // + leaf A entries under root B entries (Q5)
     if (mb < (1ull << 40)) {
         // what a stream of mb bits can put on the lists ... plus what ONE chunk of the encoder appends: its scans
-        // give every entry of the chunk its list slots before the bit budget cuts the chunk short (encode.hip:
-        // up to 2048 LIP entries or 1024 LIS entries per chunk, at most four appends each; found by
+        // give every entry of the chunk its list slots before the bit budget cuts the chunk short (encode.hip: up to 2048
+        // LIP entries or 1024 LIS entries per chunk; encode_wide.hip: 8192 or 2048; at most four appends each; found by
         // tests/test_gpu_spiht.py::test_random_geometries_and_budgets)
-        const uint64_t chunk_slack = 4096;
+        const uint64_t chunk_slack = 16384;
         lip = std::min(lip, roots + mb + chunk_slack);
         lsp = std::min(lsp, mb / 2 + 1 + chunk_slack);
         lis = std::min(lis, roots + 4 * mb + chunk_slack);
@@ -415,7 +419,7 @@ extern "C" void spiht_ctx_destroy(spiht_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    DevBuf *bufs[] = {&ctx->filt, &ctx->exttmp, &ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
+    DevBuf *bufs[] = {&ctx->widebuf, &ctx->filt, &ctx->exttmp, &ctx->l1flags, &ctx->x, &ctx->dmsb, &ctx->lmsb, &ctx->maxabs, &ctx->out, &ctx->nbits, &ctx->maxn, &ctx->err,
                       &ctx->lists, &ctx->coeffs, &ctx->a0, &ctx->a1, &ctx->data, &ctx->nbytes, &ctx->rec, &ctx->mults,
                       &ctx->img, &ctx->trace, &ctx->meta, &ctx->recz, &ctx->lspcnt, &ctx->himg, &ctx->hrec, &ctx->tilebuf};
     for (DevBuf *b : bufs)
@@ -597,6 +601,27 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
     a.lip0 = lp.lip0; a.lip1 = lp.lip1; a.lsp = lp.lsp; a.lis0 = lp.lis0; a.lis1 = lp.lis1; a.lis2 = lp.lis2;
     a.err = (uint32_t *)ctx->err.p;
     memcpy(a.log2_thresh, ctx->log2_thresh, sizeof(a.log2_thresh));
+    // Few images per call: each on a group of G workgroups (encode_wide.hip) instead of one -- a single image's list coding
+    // is bound by the one CU it runs on.  Every workgroup of a group must be resident at once: B * G within the CUs.
+    static const int wide_g_env = [] { const char *e = getenv("SPIHT_WIDE_G"); return e ? atoi(e) : 0; }();
+    int G = (int)std::min<uint64_t>(64, std::max<uint64_t>(2, g.n >> 18));
+    if (wide_g_env > 0) G = wide_g_env;
+    if (ctx->opt_wide_g > 0) G = ctx->opt_wide_g;
+    G = std::min(G, ctx->num_cu / std::max(B, 1));
+    if (ctx->opt_wide_encode && wide_g_env >= 0 && G >= 2 && (g.n >= (1u << 18) || ctx->opt_wide_encode == 2) && nslots >= B) {
+        WideArgs w;
+        const uint64_t cap_max = std::max<uint64_t>(caps.lip, std::max<uint64_t>(caps.lsp, caps.lis));
+        w.maxchunks = (uint32_t)(cap_max / 2048 + 2);  // (the smaller of the two chunk sizes: WIDE_U * 1024 entries)
+        w.G = (uint32_t)G;
+        const size_t ctl_bytes = align256((size_t)B * sizeof(WideCtl)), desc_bytes = (size_t)B * 2 * w.maxchunks * 4 * 8;
+        CHK(ensure(ctx, ctx->widebuf, ctl_bytes + desc_bytes));
+        w.ctl = (WideCtl *)ctx->widebuf.p;
+        w.desc = (uint64_t *)((char *)ctx->widebuf.p + ctl_bytes);
+        StageTimer t(ctx, ST_ENC_LISTS);
+        HIPCHK(hipMemsetAsync(ctx->widebuf.p, 0, ctl_bytes + desc_bytes, ctx->stream));
+        LAUNCHCHK(spiht_launch_encode_wide(&a, &w, B, ctx->stream));
+        return SPIHT_OK;
+    }
     {
         StageTimer t(ctx, ST_ENC_LISTS);
         LAUNCHCHK(spiht_launch_encode(&a, ctx->stream));
@@ -1834,11 +1859,14 @@ extern "C" int spiht_ctx_unlock(spiht_ctx *ctx) {
 // "l1_flags" (default 1) the list decoder flags the occupied level-1 tiles for the inverse transform of the image-level
 // decode calls.  Results are the same bits whatever the setting.  Unknown name / value: SPIHT_ERR_ARG.
 extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value) {
-    if (!ctx || !name || (value != 0 && value != 1)) return SPIHT_ERR_ARG;
+    if (!ctx || !name || value < 0) return SPIHT_ERR_ARG;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
-    if (!strcmp(name, "d1_emit")) ctx->opt_d1_emit = value != 0;
-    else if (!strcmp(name, "l1_flags")) ctx->opt_l1_flags = value != 0;
-    else if (!strcmp(name, "pads_persist")) { ctx->opt_pads_persist = value != 0; ctx->pads_zeroed.clear(); }
+    const bool b01 = value == 0 || value == 1;
+    if (!strcmp(name, "d1_emit") && b01) ctx->opt_d1_emit = value != 0;
+    else if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
+    else if (!strcmp(name, "wide_encode") && value <= 2) ctx->opt_wide_encode = (int)value;
+    else if (!strcmp(name, "wide_groups") && value <= 256) ctx->opt_wide_g = (int)value;
+    else if (!strcmp(name, "pads_persist") && b01) { ctx->opt_pads_persist = value != 0; ctx->pads_zeroed.clear(); }
     else return SPIHT_ERR_ARG;
     return SPIHT_OK;
 }

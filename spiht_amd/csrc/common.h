@@ -74,6 +74,21 @@ struct EncArgs {
     float log2_thresh[32];   // log2_thresh[k]: smallest float m < 2^k with (u8)log2f(m) == k (host libm), or 2^k
 };
 
+// One image on several CUs (encode_wide.hip): per group of workgroups a control block and the descriptors of the chunk scan.
+struct WideCtl {          // zero-filled before every launch
+    uint32_t bar_count, bar_gen;  // the group's barrier: arrivals (monotonic), released epoch
+    uint32_t go;          // workgroup 0 has handed over: st[] is valid
+    uint32_t bad;         // 1: a list capacity exceeded, 2: a spin limit hit
+    uint32_t st[12];      // n, lip_len, lsp_len, lis_len, bitpos lo / hi, LIP buffer, LIS buffer, done
+    uint32_t tot[8];      // totals of the pass just finished, two sets (pass number & 1)
+};
+struct WideArgs {
+    WideCtl *ctl;         // [groups]
+    uint64_t *desc;       // [groups][2][maxchunks][4] words [pass number | count]: aggregates, inclusive prefixes; zero-filled
+    uint32_t maxchunks;
+    uint32_t G;           // workgroups per image
+};
+
 // Tile of the inverse level-1 kernels (dwt.hip), in output positions; in band positions half of it.
 #define IW_TH 24    // output rows per tile (two halves, one per half of the workgroup; a multiple of 4)
 #define IW_TW 128   // output cols per tile, one thread per column per half

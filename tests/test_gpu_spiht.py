@@ -385,3 +385,51 @@ def test_unscatter_lists_puts_the_zeros_back(oracle):
         unscatter()
         ctx.synchronize()
         assert not d_rec.download().any()
+
+
+def test_wide_encoder_matches_oracle(oracle):
+    """One image on several CUs (encode_wide.hip: chunks of a pass on a group of workgroups, decoupled look-back scan,
+    group barriers between the passes; the planes with short lists by workgroup 0 alone): forced on for every size
+    (option "wide_encode" = 2), with 2 to 40 workgroups per image -- streams equal to the oracle's, budgets that end inside
+    every kind of pass, unlimited budgets, images smaller than one chunk and images of many chunks per pass, duplicated
+    tree nodes (odd root blocks), and a small batch (several groups in one launch)."""
+    import spiht_amd
+    from spiht_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(77)
+    try:
+        ctx.set_option("wide_encode", 2)
+        cases = [(3, 300, 420, 5, 7, 3000.0), (1, 512, 512, 4, 4, 20000.0), (3, 131, 203, 3, 5, 800.0), (2, 40, 56, 5, 7, 300.0),
+                 (3, 345, 287, 11, 9, 60000.0), (4, 260, 260, 2, 2, 5000.0)]
+        for k, (c, h, w, lh, lw, scale) in enumerate(cases):
+            x = synth_coeffs(100 + k, c, h, w, lh, lw, scale=scale)
+            n = x.size
+            for G in (0, 2, 5, 16, 40):
+                ctx.set_option("wide_groups", G)
+                budgets = [UNLIMITED, n // 3, n // 11 + 13, int(rng.integers(1, n)), int(rng.integers(1, 2000))]
+                for mb in budgets[: 5 if G in (0, 5) else 2]:
+                    try:
+                        _check_encode(oracle, x, lh, lw, mb)
+                    except Exception as e:
+                        raise AssertionError("case %d (c=%d %dx%d ll %dx%d) G=%d max_bits=%d: %r" % (k, c, h, w, lh, lw, G, mb, e))
+        # a batch of four through the batched entry point: four groups side by side
+        ctx.set_option("wide_groups", 8)
+        xs = np.stack([synth_coeffs(200 + b, 3, 200, 280, 7, 9, scale=4000.0) for b in range(4)])
+        import ctypes as C
+        from spiht_amd.batch import DeviceArray
+        L, vp = _lib.lib(), C.c_void_p
+        mb, slot = 150000, (150000 // 8 + 8) // 4 * 4
+        d_x, d_out = DeviceArray(ctx, xs.shape, np.int32), DeviceArray(ctx, (4, slot), np.uint8)
+        d_nbits, d_maxn = DeviceArray(ctx, (4,), np.uint64), DeviceArray(ctx, (4,), np.uint8)
+        d_x.upload(xs)
+        _lib.check(L.spiht_encode_batch_i32(ctx.handle, vp(d_x.ptr), 4, 3, 200, 280, 7, 9, mb, vp(d_out.ptr), slot, vp(d_nbits.ptr),
+                                            vp(d_maxn.ptr)))
+        out, nbits, maxn = d_out.download(), d_nbits.download(), d_maxn.download()
+        for b in range(4):
+            d_ref, n_ref, nb_ref = oracle.encode_nbits(xs[b], 7, 9, mb)
+            assert int(nbits[b]) == nb_ref and int(maxn[b]) == n_ref and out[b, :len(d_ref)].tobytes() == d_ref, b
+        for a_ in (d_x, d_out, d_nbits, d_maxn):
+            a_.free()
+    finally:
+        ctx.set_option("wide_groups", 0)
+        ctx.set_option("wide_encode", 1)
