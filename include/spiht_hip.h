@@ -261,7 +261,12 @@ int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, con
  * the occupancy words above inside the image-level decode calls; "pads_persist" (default 0): the caller promises that a
  * coefficient array this context's forward transform has filled is not written by anyone else before the same context
  * fills it again with the same geometry -- the zero padding of coeffs_to_array is then written once per array instead
- * of once per call (a caller that recycles its arrays, e.g. the pipelined schedule).  value 0 / 1. */
+ * of once per call (a caller that recycles its arrays, e.g. the pipelined schedule).  Those three: value 0 / 1.
+ * "wide_encode" (default 1): an encode call of few images (at most half as many as the device has CUs, each of 2^18
+ * coefficients or more) codes each image on a group of workgroups, one per CU, instead of one workgroup -- the latency of a
+ * single call (csrc/encode_wide.hip); 0: always one workgroup per image; 2: groups whatever the size of the image
+ * (tests).  "wide_groups" (default 0 = by image size, 2 ... 64): workgroups per image of that path, 0 ... 256.  Such
+ * launches are queued one at a time per device (their workgroups wait for one another and must all be resident). */
 int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
 
 /* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels

@@ -619,7 +619,19 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
         w.desc = (uint64_t *)((char *)ctx->widebuf.p + ctl_bytes);
         StageTimer t(ctx, ST_ENC_LISTS);
         HIPCHK(hipMemsetAsync(ctx->widebuf.p, 0, ctl_bytes + desc_bytes, ctx->stream));
-        LAUNCHCHK(spiht_launch_encode_wide(&a, &w, B, ctx->stream));
+        // The workgroups of a group wait for one another, so a grid must become resident as a whole: two such grids of
+        // different contexts, each half resident on a full GPU, would wait for ever.  One at a time per device, by an
+        // event chain between the contexts' streams (the host does not block).
+        static std::mutex wide_mu;
+        static hipEvent_t wide_last[64] = {};
+        {
+            std::lock_guard<std::mutex> wl(wide_mu);
+            hipEvent_t &ev = wide_last[ctx->device & 63];
+            if (ev) HIPCHK(hipStreamWaitEvent(ctx->stream, ev, 0));
+            else HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            LAUNCHCHK(spiht_launch_encode_wide(&a, &w, B, ctx->stream));
+            HIPCHK(hipEventRecord(ev, ctx->stream));
+        }
         return SPIHT_OK;
     }
     {

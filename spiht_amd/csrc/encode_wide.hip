@@ -29,7 +29,7 @@
 #ifndef WIDE_SOLO
 #define WIDE_SOLO 24576u  // entries on the three lists together up to which a plane is coded by workgroup 0 alone
 #endif
-#define WIDE_SPIN (1u << 20)
+#define WIDE_SPIN (1u << 25)  // some tens of seconds: other kernels may hold the CUs a workgroup of the group waits for
 
 __device__ __forceinline__ uint64_t wd_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wd_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
