@@ -433,3 +433,41 @@ def test_wide_encoder_matches_oracle(oracle):
     finally:
         ctx.set_option("wide_groups", 0)
         ctx.set_option("wide_encode", 1)
+
+
+def test_wide_encoder_from_two_contexts_at_once(oracle):
+    """Two threads, a context each, 160 workgroups per image: the two grids together exceed the CUs, and the workgroups of
+    a grid wait for one another -- half-resident twins would wait for ever.  The library chains such launches one at a
+    time per device (api.cpp: encode_lists_device); every stream must come out right, no spin limit hit."""
+    import ctypes as C
+    import threading
+    from spiht_amd import _lib
+    x = [synth_coeffs(300 + t, 3, 400, 520, 7, 9, scale=5000.0) for t in range(2)]
+    ref = [oracle.encode_nbits(x[t], 7, 9, 400000)[:2] for t in range(2)]
+    errs = []
+
+    def work(t):
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_option("wide_groups", 160)
+            L = _lib.lib()
+            c, h, w = x[t].shape
+            out = np.empty(400000 // 8 + 8, np.uint8)
+            nbits, max_n = C.c_uint64(), C.c_uint8()
+            for _ in range(12):
+                _lib.check(L.spiht_encode_i32(ctx.handle, C.c_void_p(x[t].ctypes.data), c, h, w, h * w, w, 1, 7, 9, 400000,
+                                              C.c_void_p(out.ctypes.data), out.size, C.byref(nbits), C.byref(max_n)))
+                d, n = out[: (nbits.value + 7) // 8].tobytes(), int(max_n.value)
+                if (d, n) != ref[t]:
+                    errs.append("thread %d: stream differs" % t)
+                    break
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append("thread %d: %r" % (t, e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(timeout=300)
+    assert not errs and not any(t_.is_alive() for t_ in th), errs
