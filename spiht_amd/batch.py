@@ -238,6 +238,7 @@ class OverlappedCodec:
         # in this schedule), but the transforms beside it lose less, and they are the longer queue
         for cx in self.Ls:
             cx.set_decoder_waves(decoder_waves)
+            cx.set_option("wide_encode", 0)  # (one workgroup per image whatever the batch size: see csrc/pipeline.cpp)
         self.e_first = bool(e_first)  # experiment: encoder kernel queued before the unscatter
         self.u_early = bool(u_early)  # the unscatter of a batch right behind its inverse transform (off the next list-coding chain)
         self._unscattered = [True, True]

@@ -603,12 +603,10 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
     memcpy(a.log2_thresh, ctx->log2_thresh, sizeof(a.log2_thresh));
     // Few images per call: each on a group of G workgroups (encode_wide.hip) instead of one -- a single image's list coding
     // is bound by the one CU it runs on.  Every workgroup of a group must be resident at once: B * G within the CUs.
-    static const int wide_g_env = [] { const char *e = getenv("SPIHT_WIDE_G"); return e ? atoi(e) : 0; }();
     int G = (int)std::min<uint64_t>(64, std::max<uint64_t>(2, g.n >> 18));
-    if (wide_g_env > 0) G = wide_g_env;
     if (ctx->opt_wide_g > 0) G = ctx->opt_wide_g;
     G = std::min(G, ctx->num_cu / std::max(B, 1));
-    if (ctx->opt_wide_encode && wide_g_env >= 0 && G >= 2 && (g.n >= (1u << 18) || ctx->opt_wide_encode == 2) && nslots >= B) {
+    if (ctx->opt_wide_encode && G >= 2 && (g.n >= (1u << 18) || ctx->opt_wide_encode == 2) && nslots >= B) {
         WideArgs w;
         const uint64_t cap_max = std::max<uint64_t>(caps.lip, std::max<uint64_t>(caps.lsp, caps.lis));
         w.maxchunks = (uint32_t)(cap_max / 2048 + 2);  // (the smaller of the two chunk sizes: WIDE_U * 1024 entries)

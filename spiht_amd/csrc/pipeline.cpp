@@ -96,6 +96,9 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
         if ((st = spiht_ctx_create(device, &p->Lc[s])) != SPIHT_OK) break;
         // decoder workgroups of 8 wavefronts: a longer walk, a lighter neighbour for the transforms beside it
         if ((st = spiht_ctx_set_decoder_waves(p->Lc[s], 8)) != SPIHT_OK) break;
+        // one workgroup per image whatever the batch size: the several-CUs-per-image encoder is for single calls -- its
+        // workgroups take a whole CU each and would wait for the transforms beside them to leave one
+        if ((st = spiht_ctx_set_option(p->Lc[s], "wide_encode", 0)) != SPIHT_OK) break;
         if ((st = spiht_event_create(p->Hc, &p->ev_a[s])) != SPIHT_OK) break;
         if ((st = spiht_event_create(p->Lc[s], &p->ev_d[s])) != SPIHT_OK) break;
         if ((st = spiht_event_create(p->Hc, &p->ev_i[s])) != SPIHT_OK) break;
