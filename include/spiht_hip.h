@@ -265,7 +265,8 @@ int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, con
  * "wide_encode" (default 1): an encode call of few images (at most half as many as the device has CUs, each of 2^18
  * coefficients or more) codes each image on a group of workgroups, one per CU, instead of one workgroup -- the latency of a
  * single call (csrc/encode_wide.hip); 0: always one workgroup per image; 2: groups whatever the size of the image
- * (tests).  "wide_groups" (default 0 = by image size, 2 ... 64): workgroups per image of that path, 0 ... 256.  Such
+ * (tests).  "wide_groups" (default 0 = by image size, 2 ... 64): workgroups per image of that path, 0 ... 256;
+ * "wide_solo" (default 24576): list entries up to which a bit plane is still coded by the group's first workgroup alone.  Such
  * launches are queued one at a time per device (their workgroups wait for one another and must all be resident). */
 int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
 

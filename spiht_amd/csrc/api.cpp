@@ -109,6 +109,7 @@ struct spiht_ctx {
     DevBuf l1flags;             // L1Flags words of the fused decode path
     DevBuf exttmp;              // intermediates of the two-pass forward level (extension modes that compute their samples)
     DevBuf widebuf;             // control blocks and scan descriptors of the several-CUs-per-image encoder (encode_wide.hip)
+    int opt_wide_solo = 24576;  // list entries up to which a plane stays with workgroup 0 (4 k ... 64 k measured the same)
     int opt_wide_g = 0;         // workgroups per image of that encoder (0: by the size of the image)
     int opt_wide_encode = 1;    // few images per call: one image on several CUs (2: whatever the image's size -- tests)
     DevBuf filt;                // the filters of wavelet `filt_wavelet` on the device, for the two-pass levels (any length)
@@ -611,6 +612,8 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
         const uint64_t cap_max = std::max<uint64_t>(caps.lip, std::max<uint64_t>(caps.lsp, caps.lis));
         w.maxchunks = (uint32_t)(cap_max / 2048 + 2);  // (the smaller of the two chunk sizes: WIDE_U * 1024 entries)
         w.G = (uint32_t)G;
+        w.solo = (uint32_t)ctx->opt_wide_solo;
+        w.pad = 0;
         const size_t ctl_bytes = align256((size_t)B * sizeof(WideCtl)), desc_bytes = (size_t)B * 2 * w.maxchunks * 4 * 8;
         CHK(ensure(ctx, ctx->widebuf, ctl_bytes + desc_bytes));
         w.ctl = (WideCtl *)ctx->widebuf.p;
@@ -1876,6 +1879,7 @@ extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t va
     else if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
     else if (!strcmp(name, "wide_encode") && value <= 2) ctx->opt_wide_encode = (int)value;
     else if (!strcmp(name, "wide_groups") && value <= 256) ctx->opt_wide_g = (int)value;
+    else if (!strcmp(name, "wide_solo") && value <= (1 << 30)) ctx->opt_wide_solo = (int)value;
     else if (!strcmp(name, "pads_persist") && b01) { ctx->opt_pads_persist = value != 0; ctx->pads_zeroed.clear(); }
     else return SPIHT_ERR_ARG;
     return SPIHT_OK;

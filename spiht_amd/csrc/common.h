@@ -87,6 +87,8 @@ struct WideArgs {
     uint64_t *desc;       // [groups][2][maxchunks][4] words [pass number | count]: aggregates, inclusive prefixes; zero-filled
     uint32_t maxchunks;
     uint32_t G;           // workgroups per image
+    uint32_t solo;        // entries on the three lists together up to which a plane is coded by workgroup 0 alone
+    uint32_t pad;
 };
 
 // Tile of the inverse level-1 kernels (dwt.hip), in output positions; in band positions half of it.

@@ -26,9 +26,6 @@
 #define WIDE_U 2      // LIS entries per thread and chunk (consecutive in the queue); 4: 82 registers spilled
 #endif
 #define WIDE_V 8      // LIP / LSP entries per thread and chunk; a multiple of 4
-#ifndef WIDE_SOLO
-#define WIDE_SOLO 24576u  // entries on the three lists together up to which a plane is coded by workgroup 0 alone
-#endif
 #define WIDE_SPIN (1u << 25)  // some tens of seconds: other kernels may hold the CUs a workgroup of the group waits for
 
 __device__ __forceinline__ uint64_t wd_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -308,7 +305,7 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
     }
 
     for (; !done; --n) {
-        if (solo && G > 1 && lip_len + lsp_len + lis_len >= WIDE_SOLO) {
+        if (solo && G > 1 && lip_len + lsp_len + lis_len >= w.solo) {
             // hand-over: from this plane on the group works together (workgroup 0 gets here alone)
             __syncthreads();
             if (tid == 0) {

@@ -299,14 +299,32 @@ def test_medium_realistic(oracle):
         _check_decode(oracle, full[:nb], n, x.shape, 13, 19)
 
 
-def test_random_geometries_and_budgets(oracle):
+@pytest.mark.parametrize("wide", [False, True])
+def test_random_geometries_and_budgets(oracle, wide):
     """seeded random sweep: channels, odd / even sizes, LL blocks of every parity, magnitudes from 0 to 2^29, budgets
-    from a few bits to unlimited -- stream, max_n and decoded array against the oracle, decode of random prefixes too"""
+    from a few bits to unlimited -- stream, max_n and decoded array against the oracle, decode of random prefixes too.
+    wide: the same cases through the several-CUs-per-image encoder (forced on for these small arrays, 2 to 9 workgroups)"""
     import spiht_amd
+    from spiht_amd import _lib
     rng = np.random.default_rng(20261004)
     done = 0
     n_cases = int(os.environ.get("SPIHT_SWEEP_N", "48"))  # larger sweeps on demand
+    ctx = _lib.default_context()
+    ctx.set_option("wide_encode", 2 if wide else 1)
+    try:
+        _random_cases(oracle, rng, n_cases, ctx if wide else None)
+    finally:
+        ctx.set_option("wide_encode", 1)
+        ctx.set_option("wide_groups", 0)
+        ctx.set_option("wide_solo", 24576)
+
+
+def _random_cases(oracle, rng, n_cases, wide_ctx):
+    done = 0
     while done < n_cases:
+        if wide_ctx is not None:
+            wide_ctx.set_option("wide_groups", 2 + done % 8)
+            wide_ctx.set_option("wide_solo", [0, 300, 4000][done % 3])  # (the group takes over from the first plane / early / late)
         c = int(rng.integers(1, 5))
         lh, lw = int(rng.integers(2, 9)), int(rng.integers(2, 9))
         need_h = 2 * lh if lh % 2 == 0 else 2 * lh - 1
