@@ -14,9 +14,12 @@ from spiht_amd.spiht_wrapper import SpihtSettings
 from bench import synth_image, H, W, C_IMG, LEVEL, BPP
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+# another picture than the bench's: PROF_H, PROF_W, PROF_LEVEL, PROF_WAVELET, PROF_BPP in the environment
+H, W, LEVEL = int(os.environ.get("PROF_H", H)), int(os.environ.get("PROF_W", W)), int(os.environ.get("PROF_LEVEL", LEVEL))
+BPP = float(os.environ.get("PROF_BPP", BPP))
 ctx = _lib.default_context(0)
 L = _lib.lib()
-codec = BatchCodec(C_IMG, H, W, SpihtSettings(), LEVEL, int(H * W * BPP), ctx=ctx)
+codec = BatchCodec(C_IMG, H, W, SpihtSettings(wavelet=os.environ.get("PROF_WAVELET", "bior2.2")), LEVEL, int(H * W * BPP), ctx=ctx)
 g = codec.geom
 img = synth_image(1000, C_IMG, H, W)
 d_img = DeviceArray(ctx, (B, C_IMG, H, W), np.float64)
@@ -36,7 +39,7 @@ if HOG:
     ctx2 = _lib.Context(0)
     d_coef = DeviceArray(ctx, (B, C_IMG, g["enc_h"], g["enc_w"]), np.int32)
     d_pix = DeviceArray(ctx, (B, C_IMG, g["rec_h"], g["rec_w"]), np.float64)
-    wid, mid = L.spiht_wavelet_id(b"bior2.2"), L.spiht_mode_id(b"reflect")
+    wid, mid = L.spiht_wavelet_id(os.environ.get("PROF_WAVELET", "bior2.2").encode()), L.spiht_mode_id(b"reflect")
     ctx2.memset(d_coef.ptr, 0, d_coef.nbytes)
     ctx2.synchronize()
 ctx.set_timing(True)
