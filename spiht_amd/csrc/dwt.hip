@@ -1672,8 +1672,11 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     if (a.mode != 4) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
     const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
+#if DW_TH == 12  // (the code writer of option d1_emit is laid out for tiles of 12 rows; other heights: tile-size experiments)
     if (a.dmsb) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    else
+#endif
+    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
     if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
