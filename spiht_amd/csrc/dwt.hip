@@ -83,6 +83,22 @@ __device__ __forceinline__ void block_raise_max(uint32_t *p, uint32_t v, uint32_
     }
 }
 
+// The same for kernels whose threads are a flat index over planes (a wavefront may straddle two images): one atomic per
+// wavefront when all its lanes belong to one image, per lane otherwise.  img < 0: the lane has nothing to report.  All lanes
+// of the wavefront call it.  (One atomic per THREAD on one word per image made the two-pass forward level 17 ms per 1080p
+// picture: six million atomics on the same address.)
+__device__ __forceinline__ void wave_raise_max(uint32_t *maxabs, int img, uint32_t v) {
+    const int any = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(img, __builtin_ctzll(__ballot(img >= 0) | (1ull << 63))));
+    if (__ballot(img >= 0) == 0) return;
+    if (__all(img < 0 || img == any)) {
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
+        if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(&maxabs[any], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&maxabs[any], v);
+    } else if (img >= 0 && v) {
+        atomicMax(&maxabs[img], v);
+    }
+}
+
 __device__ __forceinline__ int ext_index(int i, int N, int mode) {
     if (i >= 0 && i < N) return i;
     switch (mode) {
@@ -928,6 +944,7 @@ __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
     const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t per = (size_t)a.out_h * a.out_w;
     uint32_t amax = 0;
+    int img = -1;
     if (t < per * (size_t)a.planes) {
         const int plane = (int)(t / per);
         const size_t r = t - (size_t)plane * per;
@@ -954,8 +971,9 @@ __global__ __launch_bounds__(256) void k_dwt_pack_ext(DwtPackArgs a) {
         co[(size_t)(a.off_h + oh) * a.enc_w + ow] = qda;
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;
         amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
-        if (a.maxabs != nullptr && amax) atomicMax(&a.maxabs[plane / a.c], amax);
+        img = plane / a.c;
     }
+    if (a.maxabs != nullptr) wave_raise_max(a.maxabs, img, amax);
 }
 // tmp: 6 arrays of planes*out_h*in_w (2) and planes*out_h*out_w (4) elements (float when a->f32), carved by the caller
 // d_filt: the wavelet's filters on the device -- dec_lo, dec_hi, rec_lo, rec_hi (F doubles each), then dec_lo, dec_hi as the
@@ -1128,12 +1146,20 @@ __global__ __launch_bounds__(256) void k_zero_pads(PadRects pr, int32_t *coeffs)
 __global__ __launch_bounds__(256) void k_quant_plain(const double *in, int32_t *out, size_t n_per_plane, int planes, int c,
                                                      const double *mults, double q, uint32_t *maxabs) {
     size_t total = n_per_plane * (size_t)planes;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        int plane = (int)(t / n_per_plane);
-        bool has_m = mults != nullptr;
-        int32_t v = quant(in[t], has_m ? mults[plane % c] : 1.0, q, has_m);
-        out[t] = v;
-        if (maxabs != nullptr && v != 0) atomicMax(&maxabs[plane / c], iabs_u(v));
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t0 = (size_t)blockIdx.x * blockDim.x; t0 < total; t0 += stride) {  // (t0: the same in every lane of a wavefront's block)
+        const size_t t = t0 + threadIdx.x;
+        int img = -1;
+        uint32_t av = 0;
+        if (t < total) {
+            int plane = (int)(t / n_per_plane);
+            bool has_m = mults != nullptr;
+            int32_t v = quant(in[t], has_m ? mults[plane % c] : 1.0, q, has_m);
+            out[t] = v;
+            img = plane / c;
+            av = iabs_u(v);
+        }
+        if (maxabs != nullptr) wave_raise_max(maxabs, img, av);
     }
 }
 __global__ __launch_bounds__(256) void k_dequant_plain(const int32_t *in, double *out, size_t n_per_plane, int planes, int c,
