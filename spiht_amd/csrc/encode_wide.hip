@@ -423,9 +423,13 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
                     const uint32_t before = t0 < cnt ? t0 : cnt;
                     const uint32_t nact = t0 >= cnt ? 0u : ((cnt - t0) < U ? (cnt - t0) : U);
                     uint32_t e[U];
-                    if (nact == U && U == 4) {
-                        const uint4 ee = *reinterpret_cast<const uint4 *>(cur + base + t0);
-                        e[0] = ee.x; e[1 % U] = ee.y; e[2 % U] = ee.z; e[3 % U] = ee.w;
+                    if constexpr (U == 2) {
+                        if (nact == 2) {  // (the queues are 256-byte aligned)
+                            const uint2 ee = *reinterpret_cast<const uint2 *>(cur + base + t0);
+                            e[0] = ee.x; e[1] = ee.y;
+                        } else {
+                            e[0] = nact ? cur[base + t0] : 0u; e[1] = 0u;
+                        }
                     } else {
 #pragma unroll
                         for (uint32_t u = 0; u < U; u++) e[u] = u < nact ? cur[base + t0 + u] : 0u;
