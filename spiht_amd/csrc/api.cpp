@@ -2010,6 +2010,16 @@ extern "C" int spiht_debug_spin(spiht_ctx *ctx, int blocks, int threads, uint64_
     return SPIHT_OK;
 }
 
+extern "C" int spiht_launch_spin_kind(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, int mode, hipStream_t st);
+// diagnostic: ... with workgroups that do one kind of work (pyramid.hip: k_spin_kind)
+extern "C" int spiht_debug_spin_kind(spiht_ctx *ctx, int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, int mode) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    LAUNCHCHK(spiht_launch_spin_kind(blocks, threads, ticks, lds_bytes, (uint32_t *)ctx->err.p + 8, mode, ctx->stream));
+    return SPIHT_OK;
+}
+
 extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
     if (!ctx || !out64) return SPIHT_ERR_ARG;
     HIPCHK(hipSetDevice(ctx->device));

@@ -163,7 +163,16 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
 
     // input row needed for output row o, tap j: 2*o + 1 - j ; first needed row r0 = 2*oh0 + 1 - (F-1)
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
+#ifndef DWT_SCALAR_ROWS
+    // the rows' element offsets (row index * in_w; -1: a row of zeros), worked out once per tile by NR threads
+    __shared__ long long s_off[NR];
+    if (tid < NR) {
+        const int gr = ext_index(r0 + tid, a.in_h, a.mode);
+        s_off[tid] = gr < 0 ? -1ll : (long long)gr * a.in_w;
+    }
+#else
     if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
+#endif
     __shared__ uint32_t s_amax;
     if (tid == 0) s_amax = 0;
     __syncthreads();
@@ -172,11 +181,33 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     if (tid < NC) {
         const int gc = ext_index(c0 + tid, a.in_w, a.mode);
         double x[NR];
+#ifndef DWT_SCALAR_ROWS
+        // Nothing of the address arithmetic on the scalar unit: a list-coding workgroup on the same CU keeps that unit busy
+        // (its sequencer wavefront issues a dependent scalar instruction whenever it can, and it is the older wavefront),
+        // and 28 rows x a dozen scalar instructions per tile were what this kernel lost beside it (DESIGN.md 6, round 3:
+        // one scalar-busy wavefront per CU and nothing else cost this kernel 68 %).  The row offsets come out of LDS
+        // through an index the compiler cannot prove uniform, so that they stay in vector registers.
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        if (a.mode != 3) {  // not zero padding: every index is inside the picture
+#pragma unroll
+            for (int r = 0; r < NR; r++) x[r] = in[s_off[r + lz] + gc];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const long long off = s_off[r + lz];
+                const bool ok = gc >= 0 && off >= 0;
+                const double v = in[ok ? off + gc : 0];
+                x[r] = ok ? v : 0.0;
+            }
+        }
+#else
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             const int gr = s_row[r];
             x[r] = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
         }
+#endif
         const int par = tid & 1, hc = tid >> 1;
 #pragma unroll
         for (int o = 0; o < DW_TH; o++) {
@@ -274,7 +305,15 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     __builtin_amdgcn_s_setprio(DWT_PRIO);
 #endif
     uint32_t tbx, tby, tbz;
+#ifndef DWT_SCALAR_SETUP
+    // the tile's coordinates worked out in vector registers (every lane the same values): the two divisions and everything
+    // that follows from them -- plane, origin, the base pointers -- then cost the scalar unit nothing (see dwt_tile)
+    uint32_t lin = blockIdx.x;
+    asm volatile("" : "+v"(lin));
+    xcd_tile_at(lin, (a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+#else
     xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
+#endif
     dwt_tile<F, LOM, HIM, PS, NR, EMIT>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
 }
 

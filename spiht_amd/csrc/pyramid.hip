@@ -452,6 +452,55 @@ __global__ __launch_bounds__(512) void k_spin(uint64_t ticks, uint32_t lds_words
     if (lds_words) dyn[threadIdx.x % lds_words] = acc;
     if (acc == 0xFFFFFFFFu) *sink = acc;
 }
+// ... and neighbours that are NOT idle, one kind of activity each (tools/corun_kinds.py): what of a list-coding workgroup's
+// doings costs the transform kernels beside it?  mode 1: wavefront 0 runs a dependent scalar chain (the sequencer's kind of
+// work), the others sleep; 2: every wavefront polls LDS between short sleeps (the workers'); 3: wavefront 0 runs a dependent
+// vector chain; 4: wavefront 0 scalar chain + wavefront 1 vector / LDS work (sequencer + helper); 5: every wavefront issues
+// scalar work (no sleeps at all).
+__device__ __forceinline__ void spin_kind_body(uint64_t ticks, uint32_t lds_words, uint32_t *sink, int mode) {
+    extern __shared__ uint32_t dyn[];
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t acc = threadIdx.x, s = (uint32_t)ticks | 1u, sb = 5u;  // (s, sb: wave-uniform, kept in SGPRs by the asm below)
+    const bool salu = (mode == 1 && wave == 0) || (mode == 4 && wave == 0) || mode == 5;
+    const bool valu = (mode == 3 && wave == 0) || (mode == 4 && wave == 1);
+    const bool poll = mode == 2;
+    for (;;) {
+        if (salu) {
+            uint32_t s1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s), b1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)sb);
+#pragma unroll
+            for (int k = 0; k < 64; k++) {  // dependent scalar chain
+                asm volatile("s_lshr_b32 %0, %0, 1\n\ts_add_i32 %0, %0, %1\n\ts_ff1_i32_b32 %1, %0\n\ts_add_i32 %1, %1, 3"
+                             : "+s"(s1), "+s"(b1) : : "scc");
+            }
+            s = s1; sb = b1;
+        } else if (valu) {
+#pragma unroll
+            for (int k = 0; k < 64; k++) acc = acc * 1664525u + (lds_words ? dyn[(acc >> 7) % lds_words] : 1013904223u);
+        } else if (poll) {
+            if (lds_words) acc += __hip_atomic_load(&dyn[threadIdx.x % lds_words], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_s_sleep(1);
+        } else {
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (__builtin_amdgcn_s_memtime() - t0 >= ticks) break;
+    }
+    if (lds_words) dyn[threadIdx.x % lds_words] = acc + s + sb;
+    if (acc == 0xFFFFFFFFu && s == 77u) *sink = acc;
+}
+__global__ __launch_bounds__(512) void k_spin_kind(uint64_t ticks, uint32_t lds_words, uint32_t *sink, int mode) {
+    spin_kind_body(ticks, lds_words, sink, mode);
+}
+// ... with the decoder's register footprint as well (96 VGPRs per thread)
+__global__ __launch_bounds__(512) void k_spin_kind96(uint64_t ticks, uint32_t lds_words, uint32_t *sink, int mode) {
+    asm volatile("v_mov_b32 v95, 0" ::: "v95");  // (what a kernel is given is the highest register it names)
+    spin_kind_body(ticks, lds_words, sink, mode);
+}
+extern "C" int spiht_launch_spin_kind(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, int mode, hipStream_t st) {
+    if (mode >= 16) hipLaunchKernelGGL(k_spin_kind96, dim3(blocks), dim3(threads), lds_bytes, st, ticks, lds_bytes / 4, sink, mode - 16);
+    else hipLaunchKernelGGL(k_spin_kind, dim3(blocks), dim3(threads), lds_bytes, st, ticks, lds_bytes / 4, sink, mode);
+    return (int)hipGetLastError();
+}
 extern "C" int spiht_launch_spin(int blocks, int threads, uint64_t ticks, uint32_t lds_bytes, uint32_t *sink, hipStream_t st) {
     hipLaunchKernelGGL(k_spin, dim3(blocks), dim3(threads), lds_bytes, st, ticks, lds_bytes / 4, sink);
     return (int)hipGetLastError();
