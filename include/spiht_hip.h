@@ -70,6 +70,10 @@ int spiht_event_create(spiht_ctx *ctx, spiht_event **out);
 void spiht_event_destroy(spiht_event *ev);
 int spiht_event_record(spiht_event *ev, spiht_ctx *ctx);
 int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *ev);
+/* Queues a kernel of one wavefront that does nothing for about `us` microseconds (<= 10 000): spacing between the kernels
+ * of two contexts when the order in which their workgroups reach the CUs matters (csrc/pipeline.cpp: the inverse
+ * transform's level 1 ahead of the list decoder queued beside it). */
+int spiht_ctx_pause_us(spiht_ctx *ctx, uint32_t us);
 /* The context's HIP stream (*stream is a hipStream_t) so a caller can queue its own work -- e.g. the RCCL gather of
  * the streams between encode and decode -- in order with the library's. */
 int spiht_ctx_stream(spiht_ctx *ctx, void **stream);
@@ -267,7 +271,9 @@ int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, con
  * single call (csrc/encode_wide.hip); 0: always one workgroup per image; 2: groups whatever the size of the image
  * (tests).  "wide_groups" (default 0 = by image size, 2 ... 64): workgroups per image of that path, 0 ... 256;
  * "wide_solo" (default 24576): list entries up to which a bit plane is still coded by the group's first workgroup alone.  Such
- * launches are queued one at a time per device (their workgroups wait for one another and must all be resident). */
+ * launches are queued one at a time per device (their workgroups wait for one another and must all be resident).
+ * "idwt_groups" (default 0 = 4): persistent workgroups per CU of the large inverse-transform levels; 3 leaves a list
+ * decoder's workgroup room beside them (the pipelined schedule sets it). */
 int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
 
 /* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels

@@ -32,7 +32,7 @@ _lib_lock = threading.Lock()
 
 # every symbol include/spiht_hip.h declares
 SYMBOLS = [
-    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_create_priority",
+    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_create_priority", "spiht_ctx_pause_us",
     "spiht_ctx_destroy",
     "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_event_create", "spiht_event_destroy", "spiht_event_record",
     "spiht_ctx_wait_event", "spiht_ctx_stream", "spiht_dwt_pyramid_batch_f64", "spiht_encode_lists_batch_i32",
@@ -75,6 +75,7 @@ def lib():
         L.spiht_last_hip_error.restype = C.c_char_p
         L.spiht_ctx_create.argtypes = [i32, C.POINTER(vp)]
         L.spiht_ctx_create_priority.argtypes = [i32, i32, C.POINTER(vp)]
+        L.spiht_ctx_pause_us.argtypes = [vp, C.c_uint32]
         L.spiht_ctx_destroy.argtypes = [vp]
         L.spiht_ctx_destroy.restype = None
         L.spiht_ctx_synchronize.argtypes = [vp]

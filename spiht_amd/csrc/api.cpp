@@ -93,7 +93,7 @@ struct spiht_ctx {
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
     DevBuf tilebuf;      // tile counters of the persistent inverse-transform kernel
-    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}};
+    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, 0};
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
@@ -1877,6 +1877,7 @@ extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t va
     const bool b01 = value == 0 || value == 1;
     if (!strcmp(name, "d1_emit") && b01) ctx->opt_d1_emit = value != 0;
     else if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
+    else if (!strcmp(name, "idwt_groups") && value <= 8) ctx->tilectr.wg_per_cu = (int32_t)value;
     else if (!strcmp(name, "wide_encode") && value <= 2) ctx->opt_wide_encode = (int)value;
     else if (!strcmp(name, "wide_groups") && value <= 256) ctx->opt_wide_g = (int)value;
     else if (!strcmp(name, "wide_solo") && value <= (1 << 30)) ctx->opt_wide_solo = (int)value;
@@ -1986,6 +1987,17 @@ extern "C" int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *e) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamWaitEvent(ctx->stream, e->ev, 0));
+    return SPIHT_OK;
+}
+
+extern "C" int spiht_launch_pause(uint64_t ticks, hipStream_t st);
+// queues a kernel of one wavefront that does nothing for about `us` microseconds (at most 10 000)
+extern "C" int spiht_ctx_pause_us(spiht_ctx *ctx, uint32_t us) {
+    if (!ctx || us > 10000u) return SPIHT_ERR_ARG;
+    if (us == 0) return SPIHT_OK;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    LAUNCHCHK(spiht_launch_pause((uint64_t)us * 2400u, ctx->stream));  // (s_memtime counts shader clocks, 2.1-2.4 GHz)
     return SPIHT_OK;
 }
 

@@ -239,6 +239,7 @@ struct DwtKArgs {
 struct TileCtr {
     uint32_t *dev;      // 8 counters, 32 words apart (a memory line each); zero when allocated
     uint32_t base[8];   // host-side: value of each counter before the next launch
+    int32_t wg_per_cu;  // persistent workgroups per CU of the next launches (0: the kernel's default, IWP_WG)
 };
 struct TileBase { uint32_t v[8]; };
 

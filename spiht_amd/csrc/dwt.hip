@@ -1777,7 +1777,7 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
     // a level with several tiles per workgroup slot: persistent workgroups that fetch a tile ahead
     static const uint32_t pf_min = [] { const char *e = getenv("SPIHT_IDWT_PF_MIN"); return e ? (uint32_t)atol(e) : 20000u; }();
     if (pf && tc && num_cu >= 2 && nt >= pf_min && (uint64_t)(a.out_h + IW_TH) * a.out_w * 8u < (1ull << 31)) {  // (>= 8 workgroups: one per tile range at least)
-        const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : IWP_WG));
+        const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : (tc->wg_per_cu > 0 ? tc->wg_per_cu : IWP_WG)));
         static const int dyn = [] { const char *e = getenv("SPIHT_IDWT_DYN"); return e ? atoi(e) : 1; }();
         TileBase cb;
         uint32_t *ctr = (tc && dyn) ? tc->dev : nullptr;

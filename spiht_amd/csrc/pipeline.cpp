@@ -37,6 +37,8 @@ struct spiht_pipeline {
     spiht_ctx *Hc = nullptr, *Lc[2] = {nullptr, nullptr};
     bool owns_h = true;   // false: the caller's context (spiht_pipeline_create_on)
     spiht_event *ev_a[2] = {nullptr, nullptr}, *ev_d[2] = {nullptr, nullptr}, *ev_i[2] = {nullptr, nullptr};
+    spiht_event *ev_c = nullptr;  // the coarse levels of the pending inverse transform are through
+    double *approx = nullptr;     // what they leave for its level 1 (spiht_idwt_approx_shape)
     // two buffer sets
     int32_t *coeffs[2] = {nullptr, nullptr}, *rec[2] = {nullptr, nullptr};
     uint8_t *dmsb[2] = {nullptr, nullptr}, *lmsb[2] = {nullptr, nullptr};
@@ -64,10 +66,12 @@ static void pipeline_free(spiht_pipeline *p) {
             spiht_event_destroy(p->ev_i[s]);
         }
     }
+    if (p->Hc && p->approx) (void)spiht_dev_free(p->Hc, p->approx);
+    spiht_event_destroy(p->ev_c);
     for (int s = 0; s < 2; s++)
         if (p->Lc[s]) spiht_ctx_destroy(p->Lc[s]);
     if (p->Hc && p->owns_h) spiht_ctx_destroy(p->Hc);
-    else if (p->Hc) (void)spiht_ctx_set_option(p->Hc, "pads_persist", 0);
+    else if (p->Hc) { (void)spiht_ctx_set_option(p->Hc, "pads_persist", 0); (void)spiht_ctx_set_option(p->Hc, "idwt_groups", 0); }
     delete p;
 }
 
@@ -113,6 +117,16 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
         }
         if (st == SPIHT_OK) st = spiht_dev_memset(p->Hc, p->rec[s], 0, (uint64_t)B * n * 4);  // zero once: U keeps it zero
     }
+    if (st == SPIHT_OK) st = spiht_event_create(p->Hc, &p->ev_c);
+    if (st == SPIHT_OK) {
+        int64_t a_h = 0, a_w = 0;
+        st = spiht_idwt_approx_shape(H, W, wavelet, level, &a_h, &a_w);
+        if (st == SPIHT_OK && a_h > 0 && a_w > 0 && mode != SPIHT_MODE_PERIODIZATION)
+            st = spiht_dev_alloc(p->Hc, (uint64_t)B * c * a_h * a_w * 8, (void **)&p->approx);
+    }
+    // three persistent inverse-transform workgroups per CU instead of four: a decoder workgroup that arrives behind them
+    // still fits (registers), see queue_inverse_*
+    if (st == SPIHT_OK) (void)spiht_ctx_set_option(p->Hc, "idwt_groups", 3);
     if (st == SPIHT_OK) st = spiht_ctx_synchronize(p->Hc);
     if (st != SPIHT_OK) { pipeline_free(p); return st; }
     *out = p;
@@ -155,15 +169,35 @@ extern "C" int spiht_pipeline_set_color3(spiht_pipeline *p, const double *A_f, c
     return spiht_ctx_set_color3(p->Hc, A_f, M_f, p_f, A_i, M_i, p_i);  // (the contexts are the pipeline's own: set for good)
 }
 
-static int queue_inverse(spiht_pipeline *p, int s, double *d_img_out) {
+// The inverse transform of batch s in two parts.  Part 1: the coarse levels, queued beside the encoder of the batch after it;
+// ev_c marks their end.  Part 2: level 1.  The decoder of the batch after waits for ev_c, so that it starts together with
+// level 1 -- whose launch stands right behind ev_c in its own queue and so reaches the CUs first.  That order matters: a CU
+// serves the older wavefronts first, and the inverse level 1 beside a decoder that got there first takes
+// 4.4 ms, with the decoder behind it 3.75.  Without an approximation buffer (periodization, fewer than two levels) part 1
+// is empty and part 2 the whole transform.
+static int queue_inverse_coarse(spiht_pipeline *p, int s) {
     CHK(spiht_ctx_wait_event(p->Hc, p->ev_d[s]));
-    CHK(spiht_dequant_idwt_flags_batch_f64(p->Hc, p->rec[s], p->flags[s], p->B, p->c, p->H, p->W, p->wavelet, p->mode, p->level,
-                                           p->q, p->mp(), d_img_out));
+    if (p->approx)
+        CHK(spiht_idwt_coarse_batch_f64(p->Hc, p->rec[s], p->B, p->c, p->H, p->W, p->wavelet, p->mode, p->level, p->q, p->mp(), p->approx));
+    CHK(spiht_event_record(p->ev_c, p->Hc));
+    return SPIHT_OK;
+}
+static int queue_inverse_level1(spiht_pipeline *p, int s, double *d_img_out) {
+    if (p->approx)
+        CHK(spiht_idwt_level1_flags_batch_f64(p->Hc, p->rec[s], p->approx, p->flags[s], p->B, p->c, p->H, p->W, p->wavelet, p->mode,
+                                              p->level, p->q, p->mp(), d_img_out));
+    else
+        CHK(spiht_dequant_idwt_flags_batch_f64(p->Hc, p->rec[s], p->flags[s], p->B, p->c, p->H, p->W, p->wavelet, p->mode, p->level,
+                                               p->q, p->mp(), d_img_out));
     CHK(spiht_event_record(p->ev_i[s], p->Hc));
     // ... and the zeros back into the array as soon as that has read it, on the batch's own list-coding context
     CHK(spiht_ctx_wait_event(p->Lc[s], p->ev_i[s]));
     CHK(spiht_unscatter_lists_batch_i32(p->Lc[s], p->rec[s], p->B, p->c, p->enc_h, p->enc_w));
     return SPIHT_OK;
+}
+static int queue_inverse(spiht_pipeline *p, int s, double *d_img_out) {
+    CHK(queue_inverse_coarse(p, s));
+    return queue_inverse_level1(p, s, d_img_out);
 }
 
 extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits,
@@ -193,13 +227,23 @@ extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_i
         x_maxn = d_all_max_n + (uint64_t)rank * p->B;
     }
     CHK(spiht_nbits_to_nbytes(L, x_nbits, p->B, p->nbytes[s]));
+    // H: the coarse levels of the previous batch's inverse transform (beside this batch's encoder) ...
+    if (p->pending) {
+        CHK(queue_inverse_coarse(p, p->pending_slot));
+        CHK(spiht_ctx_wait_event(L, p->ev_c));  // ... this batch's decoder not before they are through,
+        // and a little later still: level 1's persistent workgroups (three per CU, launched at that moment) should have
+        // settled evenly before the decoder's arrive -- dispatched in the same microseconds, some CUs end up with four of
+        // them and no room for a decoder workgroup until the whole level is through (decoder 13.9 instead of 10 ms)
+        static const uint32_t gap_us = getenv("SPIHT_PIPELINE_GAP_US") ? (uint32_t)atoi(getenv("SPIHT_PIPELINE_GAP_US")) : 100u;
+        CHK(spiht_ctx_pause_us(L, gap_us));
+    }
     CHK(spiht_decode_lists_flags_batch_i32(L, x_out, p->slot_stride, p->nbytes[s], x_maxn, p->B, p->c, p->H, p->W, p->wavelet,
                                            p->mode, p->level, p->rec[s], p->flags[s]));
     CHK(spiht_event_record(p->ev_d[s], L));
     p->used[s] = true;
-    // H: back half of the previous batch's decoder (beside this batch's decoder)
+    // H: ... and its level 1 (beside this batch's decoder, and there first)
     if (p->pending) {
-        CHK(queue_inverse(p, p->pending_slot, p->pending_out));
+        CHK(queue_inverse_level1(p, p->pending_slot, p->pending_out));
         p->pending = false;
     }
     p->pending = true;

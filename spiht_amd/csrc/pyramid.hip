@@ -439,6 +439,18 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
     return (int)hipGetLastError();
 }
 
+// One wavefront that does nothing for about `ticks` shader clocks (spiht_ctx_pause_us): spacing between the kernels of two
+// contexts when the order in which their workgroups reach the CUs matters (csrc/pipeline.cpp).
+__global__ __launch_bounds__(64) void k_pause(uint64_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    uint32_t guard = 0;
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(16);
+}
+extern "C" int spiht_launch_pause(uint64_t ticks, hipStream_t st) {
+    hipLaunchKernelGGL(k_pause, dim3(1), dim3(64), 0, st, ticks);
+    return (int)hipGetLastError();
+}
+
 #ifdef SPIHT_DIAG
 // diagnostic (tools/corun.py): workgroups that occupy the CUs for a given number of clock ticks without touching memory
 __global__ __launch_bounds__(512) void k_spin(uint64_t ticks, uint32_t lds_words, uint32_t *sink) {
