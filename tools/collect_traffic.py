@@ -64,7 +64,7 @@ def level1(c):
 
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-ONLY = sys.argv[2] if len(sys.argv) > 2 else None  # "idwtf": only the inverse level 1 with occupancy words, into the committed file
+ONLY = sys.argv[2] if len(sys.argv) > 2 else None  # "idwtf": only the inverse level 1 with occupancy words, into the committed file; "dwt": only the forward level 1
 if ONLY == "idwtf":
     other = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic_other.json")))
     assert other["images_per_launch"] == B
@@ -89,6 +89,8 @@ out = {"images_per_launch": B, "kernels": ["%s grid %d" % k for k in k1],
        "algorithmic_bytes_per_image": 3 * (1080 * 1920 * 8 + 542 * 962 * 20)}
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "dwt_l1_traffic.json"), "w"), indent=1)
 print(json.dumps(out))
+if ONLY == "dwt":  # the forward level 1 alone (its kernel changed: the other files stand)
+    sys.exit(0)
 # inverse level 1 (largest grid of k_idwt_level) and the pyramid (all rounds of k_pyr_round + k_pyr_ll are small)
 other = {"images_per_launch": B}
 c = counters("idwt", "k_idwt_level_pf")  # the persistent kernel takes the large levels (one grid size: see counters())
