@@ -148,25 +148,10 @@ def main():
                          "on; float32 runs the single-precision forward transform PyWavelets would run on such pixels (half the "
                          "DWT read traffic); the decode side is float64 either way, as in the reference")
     ap.add_argument("--pipeline", type=int, default=1,
-                    help="1 (default) / 2: steps are software-pipelined, queued by the library's own spiht_pipeline_submit (1) or from "
-                         "Python by OverlappedCodec (2; also taken when --pair / --decoder-waves / --l1-flags ask for a variant) -- the HBM-bound halves (DWT + pyramid of step i+1, "
-                         "inverse DWT of step i-1) run on one context while step i is list-coded on another "
-                         "(spiht_amd/batch.py:OverlappedCodec); all K steps complete inside the timed region.  "
+                    help="1 (default): steps are software-pipelined, queued by the library's own spiht_pipeline_submit (csrc/pipeline.cpp) "
+                         "-- the HBM-bound halves (DWT + pyramid of step i+1, inverse DWT of step i-1) run on one context while step i is "
+                         "list-coded on another; all K steps complete inside the timed region.  "
                          "0: every step runs its stages back to back on one stream, each kernel with the whole GPU")
-    ap.add_argument("--pair", choices=["forward", "inverse"], default="inverse",
-                    help="what the list decoder of step i shares the GPU with in the pipelined schedule: the forward transform of "
-                         "step i+1 or the inverse transform of step i-1 (default; OverlappedCodec)")
-    ap.add_argument("--l1-flags", type=int, default=1,
-                    help="1 (default): the list decoder flags the occupied level-1 tiles and the inverse transform does not read the "
-                         "detail bands of the others (include/spiht_hip.h: spiht_decode_lists_flags_batch_i32); 0: reads everything")
-    ap.add_argument("--coarse-first", type=int, default=0,
-                    help="experiment (--pipeline 2): the coarse inverse levels of step i-1 between the transform and the pyramid of "
-                         "step i, where the list-coding streams are idle")
-    ap.add_argument("--d1-emit", type=int, default=0,
-                    help="1: level 1 of the forward transform writes pyramid codes ahead of the pyramid pass (measured, not the "
-                         "default: DESIGN.md 6)")
-    ap.add_argument("--decoder-waves", type=int, default=8, choices=[8, 12],
-                    help="wavefronts per decoder workgroup in the pipelined schedule (12: the library's default for single calls)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (library contexts) the batch is split over.  Measured on MI355X/ROCm 7.2: chunks on "
                          "separate streams did not overlap (2 streams = same time, 4 and 8 slower), so the default is 1")
@@ -206,8 +191,6 @@ def main():
     from spiht_amd.spiht_wrapper import SpihtSettings
 
     ctx = _lib.default_context(local_rank)
-    ctx.set_option("l1_flags", args.l1_flags)
-    ctx.set_option("d1_emit", args.d1_emit)
     comm = group = None
     comm_error = None
     if use_comm:
@@ -231,9 +214,6 @@ def main():
     max_bits = int(H * W * BPP)  # demonstrate.py:50
     K = max(1, min(args.streams, B))
     ctxs = [ctx] + [_lib.Context(local_rank) for _ in range(K - 1)]
-    for cx in ctxs[1:]:
-        cx.set_option("l1_flags", args.l1_flags)
-        cx.set_option("d1_emit", args.d1_emit)
     settings = SpihtSettings(WAVELET, QSCALE, MODE)
     codecs = [BatchCodec(C_IMG, H, W, settings, LEVEL, max_bits, ctx=cx, pixel_dtype=pix) for cx in ctxs]
     codec = codecs[0]
@@ -282,33 +262,18 @@ def main():
         codecs[k].nbits_to_nbytes(sn + a * 8, b - a, d_nbytes.ptr + a * 8)
         codecs[k].decode_device(so + a * slot, d_nbytes.ptr + a * 8, sm + a, b - a, d_rec_img.ptr + a * rec_b)
 
-    pipe = cpipe = None
-    if (args.pipeline == 1 and K == 1 and pix == np.float64 and args.pair == "inverse" and args.decoder_waves == 8 and args.l1_flags
-            and not args.coarse_first):
-        # the same schedule queued by the library itself (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): what a
-        # caller in any host language gets; three contexts of its own
+    cpipe = None
+    if args.pipeline and K == 1 and pix == np.float64:
+        # the pipelined schedule queued by the library itself (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): what a
+        # caller in any host language gets; two list-coding contexts of its own, the HBM-bound passes on `ctx`
         from spiht_amd.batch import Pipeline
         cpipe = Pipeline(codec, B)
-        pctx = cpipe.contexts()
-        pctx[0].set_option("d1_emit", args.d1_emit)
-        ctxs.extend(pctx[1:])   # (its H context is `ctx`)
-    elif args.pipeline and K == 1 and pix == np.float64:
-        # The HBM-bound halves (DWT+pyramid of step i+1, inverse DWT of step i-1) run on context H while context L
-        # list-codes step i; ordered by events, the host never blocks (spiht_amd/batch.py:OverlappedCodec).  The
-        # gather rides on the batch's list-coding stream between the encoder's and the decoder's list kernels.
-        from spiht_amd.batch import OverlappedCodec
-        pipe = OverlappedCodec(codec, B, pair=args.pair, decoder_waves=args.decoder_waves, l1_flags=bool(args.l1_flags),
-                               coarse_first=bool(args.coarse_first))
-        ctxs.extend(pipe.Ls)
+        ctxs.extend(cpipe.contexts()[1:])   # (its H context is `ctx`)
 
     def step():
         if cpipe is not None:
             cpipe.submit(d_img.ptr, out_ptr, nbits_ptr, maxn_ptr, d_rec_img.ptr, comm=comm,
                          gathered=(g_out.ptr, g_nbits.ptr, g_maxn.ptr) if comm is not None else None, rank=rank)
-            return
-        if pipe is not None:
-            pipe.submit(d_img.ptr, out_ptr, nbits_ptr, maxn_ptr, d_nbytes.ptr, d_rec_img.ptr,
-                        between=gather if comm is not None else None, dec_src=(dec_out, dec_nbits, dec_maxn))
             return
         # every call below only queues work on the chunk's own stream
         for k in range(K):
@@ -324,9 +289,7 @@ def main():
 
     def sync_all():
         if cpipe is not None:
-            cpipe.flush()
-        if pipe is not None:
-            pipe.flush()  # the inverse transform of the last step (inside the timed region)
+            cpipe.flush()  # the inverse transform of the last step (inside the timed region)
         for cx in ctxs:
             cx.synchronize()
         if group is not None:
@@ -457,7 +420,7 @@ def main():
         # the same kernels with the GPU to themselves (one serial round trip of the batch after the timed region): in
         # the pipelined schedule the numbers above are those of kernels that share the GPU with the list coder
         alone = None
-        if pipe is not None or cpipe is not None:
+        if cpipe is not None:
             own = (out_ptr, nbits_ptr, maxn_ptr)
             enc_chunk(0)
             dec_chunk(0, own)
@@ -513,7 +476,7 @@ def main():
                         other[key]["traffic_source"] = "profiles/hbm_traffic_other.json (committed PMC measurement, separate run, " \
                                                        "%s images per launch)" % ot.get("images_per_launch", "?")
                 occ = ot.get("idwt_level1_with_occupancy_words", {}).get("%g bpp" % BPP)
-                if occ and other.get("idwt_level1") is not None and args.l1_flags:
+                if occ and other.get("idwt_level1") is not None:
                     # what this run's inverse level 1 moves: the decoder's occupancy words are on, empty tiles' detail bands
                     # unread -- so its rate is quoted on the bytes it MOVES (PMC, this bit rate), not on the dense 81 MB / image
                     o1 = other["idwt_level1"]
@@ -557,12 +520,10 @@ def main():
                                    "(cfg4 shard), encode+decode, HBM-resident" % B,
                        "images_per_gpu": B, "distinct_images_per_gpu": nd, "seeds": "1000 + global image index",
                        "streams": K, "images_per_launch": per_launch,
-                       "decoder_waves": args.decoder_waves if (pipe is not None or cpipe is not None) else 12, "l1_flags": bool(args.l1_flags),
-                       "d1_emit": bool(args.d1_emit),
+                       "decoder_waves": 8 if cpipe is not None else 12,
                        "schedule": ("steps software-pipelined: HBM-bound passes of steps i+1 / i-1 on one stream while step i is "
-                                    "list-coded on another" + (", queued by the library (spiht_pipeline_submit)" if cpipe is not None
-                                                               else ", queued from Python (OverlappedCodec)")
-                                    if (pipe is not None or cpipe is not None) else "stages back to back"),
+                                    "list-coded on another, queued by the library (spiht_pipeline_submit)"
+                                    if cpipe is not None else "stages back to back"),
                        "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]],
                        "gather": (dict(comm.info(), library=_lib.lib().spiht_rccl_library().decode(),

@@ -260,12 +260,11 @@ int spiht_decode_lists_flags_batch_i32(spiht_ctx *ctx, const uint8_t *d_data, ui
 int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, const uint32_t *d_flags, int64_t B, int64_t c,
                                        int64_t H, int64_t W, int wavelet, int mode, int level, double q_scale,
                                        const double *channel_mults, double *d_img_out);
-/* Switches of this library's own making; the results are the same bits whatever they are set to.  "d1_emit" (default 0):
- * level 1 of the forward transform writes significance-pyramid codes ahead of the pyramid pass; "l1_flags" (default 1):
+/* Switches of this library's own making; the results are the same bits whatever they are set to.  "l1_flags" (default 1):
  * the occupancy words above inside the image-level decode calls; "pads_persist" (default 0): the caller promises that a
  * coefficient array this context's forward transform has filled is not written by anyone else before the same context
  * fills it again with the same geometry -- the zero padding of coeffs_to_array is then written once per array instead
- * of once per call (a caller that recycles its arrays, e.g. the pipelined schedule).  Those three: value 0 / 1.
+ * of once per call (a caller that recycles its arrays, e.g. the pipelined schedule).  Those two: value 0 / 1.
  * "wide_encode" (default 1): an encode call of few images (at most half as many as the device has CUs, each of 2^18
  * coefficients or more) codes each image on a group of workgroups, one per CU, instead of one workgroup -- the latency of a
  * single call (csrc/encode_wide.hip); 0: always one workgroup per image; 2: groups whatever the size of the image

@@ -226,8 +226,8 @@ class Context:
         check(self._lib.spiht_ctx_unlock(self.handle))
 
     def set_option(self, name, value):
-        """a switch of the library (spiht_ctx_set_option): "d1_emit", "l1_flags", "pads_persist", "wide_encode",
-        "wide_groups"; results do not depend on them"""
+        """a switch of the library (spiht_ctx_set_option): "l1_flags", "pads_persist", "wide_encode", "wide_groups",
+        "wide_solo", "idwt_groups"; results do not depend on them"""
         check(self._lib.spiht_ctx_set_option(self.handle, name.encode(), int(value)))
 
     def set_decoder_waves(self, waves):

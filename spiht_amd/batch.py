@@ -188,241 +188,12 @@ class BatchCodec:
         return out[inv]
 
 
-class OverlappedCodec:
-    """Round trips a sequence of batches with the two kinds of work on different contexts.
-
-    The transform / pyramid / inverse-transform passes are HBM-bound; the list coder is latency-bound and leaves the
-    HBM idle.  Context H runs the former, contexts L0 / L1 (alternating by batch) the latter, ordered with events only
-    (the host never blocks), so while a batch is list-coded, H already transforms the next one and inverse-transforms
-    the previous one (`pair="inverse"`, the default):
-
-        H:  A(i)               [X(i-1) done] I(i-1)   A(i+1)                 [X(i) done] I(i) ...
-        L:  [A(i), I(i-2) done] U(i-2) E(i) X(i)              [A(i+1), I(i-1) done] U(i-1) E(i+1) X(i+1) ...
-
-    A = DWT + quantise + pyramid, E / X = encoder / decoder list kernels, I = dequantise + inverse DWT, U = put the
-    zeros back into the coefficient array X(i-2) scattered into (spiht_unscatter_lists_batch_i32: through the
-    decoder's lists, which is why each of the two arrays has its own list-coding context) -- a full zero-fill per
-    batch would add 6.6 GB of writes to the HBM-bound side.  E(i+1) is ordered after X(i), so list kernels never run
-    beside one another; HBM-bound kernels never overlap one another either (one in-order stream).  Results are
-    bit-identical to BatchCodec's fused calls (same kernels).  Coefficient arrays, pyramid and decoder output are
-    double-buffered.
-
-    Resident decoder workgroups (96 VGPRs a wavefront) leave an HBM-bound kernel two or three instead of six or seven
-    workgroups per CU: whichever transform shares the GPU with the decoder loses.  The inverse transform therefore runs
-    as persistent workgroups that fetch a tile ahead (k_idwt_level_pf), and the list-coding contexts use the
-    8-wavefront build of the decoder (`decoder_waves=8`: a longer walk, a lighter neighbour): 17.6-18.0 ms per step at
-    256 x 1080p with 12 wavefronts 18.3-18.7.  Variants measured there, none better than the default:
-      pair="forward"    X(i) waits for I(i-1), so it runs beside A(i+1) and I(i-1) meets only the encoder kernel
-      split_inverse     the coarse levels of I(i) (level .. 2) behind X(i) on the list-coding stream (the encoder
-                        kernel of the next batch then waits for room on CUs full of transform workgroups)
-      l_priority        high stream priority for the list-coding contexts: no change
-      e_first           encoder kernel queued before the unscatter: worse
-    and one that is the default since the inverse transform got faster:
-      u_early           the unscatter of a batch right behind its inverse transform, on that batch's list-coding
-                        context (it then runs beside the next forward transform, which loses 2 % to its scattered
-                        writes; queued in front of the next encoder kernel it met the coarse inverse levels, and a
-                        0.02 ms launch of those took 0.47 ms): 17.5-17.7 against 17.7-18.5 ms
-    `between` (optional callable) runs between E(i) and X(i) with that batch's L context: the hook for the stream
-    gather of a multi-GPU job; `dec_src` makes the decoder read the gathered buffers."""
-
-    def __init__(self, codec, B, ctx_l=None, split_inverse=False, pair="inverse", l_priority=0, e_first=False, u_early=True,
-                 decoder_waves=8, l1_flags=True, coarse_first=False):
-        self.codec, self.B = codec, int(B)
-        if pair not in ("forward", "inverse"):
-            raise ValueError("pair must be 'forward' or 'inverse'")
-        self.pair = pair
-        self.H = codec.ctx
-        self.Ls = [ctx_l if ctx_l is not None else _lib.Context(self.H.device, l_priority),
-                   _lib.Context(self.H.device, l_priority)]
-        # decoder workgroups of 8 instead of 12 wavefronts: a longer walk (11.4 instead of 8.9 ms per 256 1080p streams
-        # in this schedule), but the transforms beside it lose less, and they are the longer queue
-        for cx in self.Ls:
-            cx.set_decoder_waves(decoder_waves)
-            cx.set_option("wide_encode", 0)  # (one workgroup per image whatever the batch size: see csrc/pipeline.cpp)
-        self.e_first = bool(e_first)  # experiment: encoder kernel queued before the unscatter
-        self.u_early = bool(u_early)  # the unscatter of a batch right behind its inverse transform (off the next list-coding chain)
-        self._unscattered = [True, True]
-        self.L = self.Ls[0]
-        g = codec.geom
-        n = codec.c * g["enc_h"] * g["enc_w"]
-        self.n = n
-        mk = lambda shape, dt: [DeviceArray(self.H, shape, dt) for _ in range(2)]  # noqa: E731
-        self.coeffs, self.rec = mk((B, n), np.int32), mk((B, n), np.int32)
-        self.dmsb, self.lmsb = mk((B, n), np.uint8), mk((B, n), np.uint8)
-        self.maxabs = mk((B,), np.uint32)
-        ah, aw = C.c_int64(), C.c_int64()
-        _lib.check(codec.L.spiht_idwt_approx_shape(codec.H, codec.W, codec.wid, codec._lv, C.byref(ah), C.byref(aw)))
-        self.split = ah.value > 0 and split_inverse  # two levels or more: coarse levels on the list-coding stream
-        # coarse_first: the coarse levels of I(i-1) between the transform and the pyramid of A(i) on H -- there the list-coding
-        # streams are idle (X(i-1) has ended, E(i) waits for the pyramid), so they run alone instead of beside the encoder
-        self.cf = ah.value > 0 and coarse_first and not self.split and pair == "inverse"
-        self.approx = mk((B, codec.c, ah.value, aw.value), np.float64) if (self.split or self.cf) else [None, None]
-        self._coarse_done = [False, False]
-        # occupancy words of the inverse transform's level-1 tiles: decoder -> inverse transform (include/spiht_hip.h)
-        nw = C.c_uint64()
-        _lib.check(codec.L.spiht_l1_flags_words(codec.c, codec.H, codec.W, codec.wid, codec.mid, codec._lv, C.byref(nw)))
-        self.flags = mk((B, nw.value), np.uint32) if nw.value and l1_flags else [None, None]
-        # the coefficient arrays are this object's own and only the forward transform writes them: their zero padding is
-        # written once per array, not once per step (beside a list decoder that launch of thin strips took 0.74 ms)
-        self.H.set_option("pads_persist", 1)
-        for r in self.rec:  # zero once; from then on U keeps them zero
-            self.H.memset(r.ptr, 0, r.nbytes)
-        self.H.synchronize()
-        self.ev_a = [_lib.Event(self.H) for _ in range(2)]    # A(i) done
-        self.ev_d = [_lib.Event(self.Ls[s]) for s in range(2)]  # X(i) done
-        self.ev_i = [_lib.Event(self.H) for _ in range(2)]    # I(i) done
-        self.used = [False, False]
-        self.i = 0
-        self._pending = None  # (slot, d_img_out) of the batch whose inverse transform has not been queued yet
-
-    def contexts(self):
-        return [self.H] + self.Ls
-
-    def close(self):
-        """give the arrays back (the promise about their padding ends with them)"""
-        if getattr(self, "coeffs", None):
-            try:
-                self.synchronize()
-            finally:
-                for d in self.coeffs + self.rec + self.dmsb + self.lmsb + self.maxabs + [f for f in self.flags if f] + \
-                        [a for a in self.approx if a]:
-                    d.free()  # (spiht_dev_free also drops what the context remembers about the array)
-                self.coeffs = None
-                self.H.set_option("pads_persist", 0)
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    def _idwt(self, s, d_img_out):
-        cd = self.codec
-        self.H.wait_event(self.ev_d[s])
-        with cd._color():  # (the colour setting of H is put on around each transform call: H may serve other codecs too)
-            if self.cf:
-                self._coarse(s)
-                self._coarse_done[s] = False
-                _lib.check(cd.L.spiht_idwt_level1_flags_batch_f64(
-                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr),
-                    C.c_void_p(self.flags[s].ptr if self.flags[s] else None), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
-                    float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
-            elif self.split:
-                _lib.check(cd.L.spiht_idwt_level1_batch_f64(
-                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.approx[s].ptr), self.B, cd.c, cd.H, cd.W,
-                    cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(d_img_out)))
-            else:
-                _lib.check(cd.L.spiht_dequant_idwt_flags_batch_f64(
-                    self.H.handle, C.c_void_p(self.rec[s].ptr), C.c_void_p(self.flags[s].ptr if self.flags[s] else None), self.B,
-                    cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, float(cd.settings.quantization_scale), cd._mults_p,
-                    C.c_void_p(d_img_out)))
-        self.H.record(self.ev_i[s])
-
-    def _coarse(self, s):
-        """coarse_first: levels level .. 2 of batch s's inverse transform on H (once)"""
-        cd = self.codec
-        if self._coarse_done[s]:
-            return
-        self.H.wait_event(self.ev_d[s])
-        _lib.check(cd.L.spiht_idwt_coarse_batch_f64(
-            self.H.handle, C.c_void_p(self.rec[s].ptr), self.B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
-            float(cd.settings.quantization_scale), cd._mults_p, C.c_void_p(self.approx[s].ptr)))
-        self._coarse_done[s] = True
-
-    def submit(self, d_img, d_out, d_nbits, d_max_n, d_nbytes, d_img_out, between=None, dec_src=None):
-        """queue the round trip of one batch (device pointers as in BatchCodec.encode_device / decode_device).
-        dec_src = (d_slots, d_nbits, d_max_n): what the decoder reads instead of the encoder's own outputs -- e.g. this
-        rank's rows of the buffers `between` gathered the streams into."""
-        cd, B, g = self.codec, self.B, self.codec.geom
-        s = self.i & 1
-        Lc = self.Ls[s]
-        vp = C.c_void_p
-        q = float(cd.settings.quantization_scale)
-        # H: front half of the encoder
-        with cd._color():
-            if self.cf:
-                _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
-                    self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
-                    vp(self.coeffs[s].ptr), None, None, vp(self.maxabs[s].ptr)))
-                if self._pending is not None:
-                    self._coarse(self._pending[0])
-                _lib.check(cd.L.spiht_pyramid_batch_i32(
-                    self.H.handle, vp(self.coeffs[s].ptr), B, cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"],
-                    vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), None))
-            else:
-                _lib.check(cd.L.spiht_dwt_pyramid_batch_f64(
-                    self.H.handle, vp(d_img), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
-                    vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr)))
-        self.H.record(self.ev_a[s])
-        # L: zeros back into the array batch i-2 was decoded into, once its inverse transform (queued on H by the
-        # previous submit) has read it ...
-        # (queued behind A(i): right after I(i-2) the forward DWT of this batch starts on H, and the scattered writes
-        # would take HBM bandwidth from it; here they run beside the next inverse transform instead)
-        if self.used[s ^ 1]:
-            Lc.wait_event(self.ev_d[s ^ 1])
-        Lc.wait_event(self.ev_a[s])
-        def unscatter():
-            if self.used[s] and not self._unscattered[s]:
-                Lc.wait_event(self.ev_i[s])
-                _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lc.handle, vp(self.rec[s].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
-                self._unscattered[s] = True
-        if not self.e_first:
-            unscatter()
-        # ... and list coding, after the previous batch's decoder on the other context
-        _lib.check(cd.L.spiht_encode_lists_batch_i32(
-            Lc.handle, vp(self.coeffs[s].ptr), vp(self.dmsb[s].ptr), vp(self.lmsb[s].ptr), vp(self.maxabs[s].ptr), B,
-            cd.c, g["enc_h"], g["enc_w"], g["ll_h"], g["ll_w"], cd.max_bits, vp(d_out), cd.slot_stride, vp(d_nbits),
-            vp(d_max_n)))
-        if self.e_first:
-            unscatter()
-        if between is not None:
-            between(Lc)
-        if self.pair == "forward" and self._pending is not None:
-            # the previous batch's inverse transform goes on H now (behind A(i)), and this batch's decoder waits for it
-            self._idwt(*self._pending)
-            Lc.wait_event(self.ev_i[self._pending[0]])
-            self._pending = None
-        x_out, x_nbits, x_max_n = dec_src if dec_src is not None else (d_out, d_nbits, d_max_n)
-        _lib.check(cd.L.spiht_nbits_to_nbytes(Lc.handle, vp(x_nbits), B, vp(d_nbytes)))
-        _lib.check(cd.L.spiht_decode_lists_flags_batch_i32(
-            Lc.handle, vp(x_out), cd.slot_stride, vp(d_nbytes), vp(x_max_n), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv,
-            vp(self.rec[s].ptr), vp(self.flags[s].ptr if self.flags[s] else None)))
-        if self.split:  # the coarse levels of this batch's inverse transform, behind its decoder
-            _lib.check(cd.L.spiht_idwt_coarse_batch_f64(
-                Lc.handle, vp(self.rec[s].ptr), B, cd.c, cd.H, cd.W, cd.wid, cd.mid, cd._lv, q, cd._mults_p,
-                vp(self.approx[s].ptr)))
-        Lc.record(self.ev_d[s])
-        self.used[s] = True
-        self._unscattered[s] = False
-        # H: back half of the previous batch's decoder (pair="inverse": beside this batch's decoder)
-        if self._pending is not None:
-            self._idwt(*self._pending)
-            if self.u_early:  # ... and the zeros back into its array as soon as that has read it, on ITS list-coding context
-                sp = self._pending[0]
-                Lp = self.Ls[sp]
-                Lp.wait_event(self.ev_i[sp])
-                _lib.check(cd.L.spiht_unscatter_lists_batch_i32(Lp.handle, vp(self.rec[sp].ptr), B, cd.c, g["enc_h"], g["enc_w"]))
-                self._unscattered[sp] = True
-        self._pending = (s, d_img_out)
-        self.i += 1
-
-    def flush(self):
-        """queue the inverse transform of the last submitted batch (call before synchronising)"""
-        if self._pending is not None:
-            self._idwt(*self._pending)
-            self._pending = None
-
-    def synchronize(self):
-        self.flush()
-        for Lc in self.Ls:
-            Lc.synchronize()
-        self.H.synchronize()
-
-
 class Pipeline:
-    """The pipelined round trip as the C ABI offers it (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): the schedule
-    of OverlappedCodec's defaults, queued by the library itself on three contexts it owns -- what a caller in any host
-    language gets, and what bench.py times.  `codec` gives geometry and settings (its context is not used)."""
+    """The pipelined round trip as the C ABI offers it (include/spiht_hip.h: spiht_pipeline_*, csrc/pipeline.cpp): consecutive
+    batches software-pipelined over three contexts -- the HBM-bound passes (transform + pyramid of step i+1, inverse transform
+    of step i-1) on one, the list coding of step i on the two others in turn --, queued by the library itself: what a caller
+    in any host language gets, and what bench.py times.  `codec` gives geometry and settings; its context runs the HBM-bound
+    passes unless own_context is set."""
 
     def __init__(self, codec, B, own_context=False):
         """own_context: the HBM-bound passes on a context of the pipeline's own instead of the codec's (one more HIP stream;

@@ -17,9 +17,7 @@
 
 extern "C" {
 int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxabs, hipStream_t st);
-int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, const D1Cover *cov,
-                         hipStream_t st);
-void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv);
+int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_encode_wide(const EncArgs *a, const WideArgs *w, int groups, hipStream_t st);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
@@ -101,7 +99,6 @@ struct spiht_ctx {
     Color3 col_fwd, col_inv;
     int dec_waves = 12;  // wavefronts per decoder workgroup (spiht_ctx_set_decoder_waves)
     // spiht_ctx_set_option
-    bool opt_d1_emit = false;   // level 1 of the forward transform writes pyramid codes ahead of the pyramid pass
     bool opt_l1_flags = true;   // the decoder flags the occupied level-1 tiles for the inverse transform
     bool opt_pads_persist = false;  // coefficient arrays this context has filled keep their zero padding (see dwt_forward)
     struct PadKey { const void *p; int planes; int64_t H, W; int F, L; };
@@ -547,10 +544,8 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
                                uint64_t *d_nbits, uint8_t *d_maxn);
 
 // Encode B device-resident coefficient arrays.  max_bits already validated; queues work on ctx->stream.
-// cov: the D codes level 1 of the forward transform has left in ctx->dmsb already (nullptr: none)
 static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int B, uint64_t max_bits_in, uint8_t *d_out,
-                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false,
-                         const D1Cover *cov = nullptr) {
+                         uint64_t slot_stride, uint64_t *d_nbits, uint8_t *d_maxn, bool have_maxabs = false) {
     if (slot_stride % 4 != 0) return SPIHT_ERR_ARG;
     if ((uint64_t)B * (uint64_t)g.c > 65535ull) return SPIHT_ERR_ARG;
     const uint64_t max_bits = max_bits_in == 0 ? SPIHT_MAX_BITS_UNLIMITED : max_bits_in;  // encoder_decoder.rs:196
@@ -572,7 +567,7 @@ static int encode_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x, int 
     }
     {
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, cov, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, B, d_x, (uint8_t *)ctx->dmsb.p, (uint8_t *)ctx->lmsb.p, ctx->stream));
     }
     return encode_lists_device(ctx, g, d_x, (const uint8_t *)ctx->dmsb.p, (const uint8_t *)ctx->lmsb.p,
                                (const uint32_t *)ctx->maxabs.p, B, max_bits, caps, nslots, lp, d_out, slot_stride, d_nbits,
@@ -1022,7 +1017,7 @@ extern "C" int spiht_pyramid_batch_i32(spiht_ctx *ctx, const int32_t *d_x, int64
     }
     {
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, (int)B, d_x, d_dmsb, d_lmsb, nullptr, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, (int)B, d_x, d_dmsb, d_lmsb, ctx->stream));
     }
     return SPIHT_OK;
 }
@@ -1117,13 +1112,8 @@ static int upload_filters(spiht_ctx *ctx, int wavelet, const double **d_filt) {
     return SPIHT_OK;
 }
 
-// d_dmsb / cov: the significance pyramid will be built over d_coeffs next (into d_dmsb [planes, enc_h, enc_w]): level 1
-// then writes the D codes it has at hand (dwt.hip: dwt_tile<.., EMIT>) and *cov says which (cov->on = 0: none)
 static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, const ImgGeom &ig, int wavelet, int mode,
-                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false,
-                       uint8_t *d_dmsb = nullptr, D1Cover *cov = nullptr) {
-    if (cov) memset(cov, 0, sizeof(*cov));
-    const bool emit_on = ctx->opt_d1_emit;
+                       double q, const double *d_mults, int32_t *d_coeffs, uint32_t *d_maxabs = nullptr, bool f32 = false) {
     const WaveletDef &wv = SPIHT_WAVELETS[wavelet];
     const size_t plane_out = (size_t)ig.enc_h * ig.enc_w;
     if (f32 && ig.L == 0) return SPIHT_ERR_ARG;
@@ -1156,7 +1146,7 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
     }
     // zero padding cells of coeffs_to_array (thin strips; every other cell is written by a band).  The transform writes
     // band cells only, so an array it has filled once for this geometry still has its zeros the next time -- PROVIDED
-    // nobody else writes into it: a caller that owns its arrays says so (option "pads_persist": OverlappedCodec's
+    // nobody else writes into it: a caller that owns its arrays says so (option "pads_persist": the pipeline's
     // double-buffered arrays; beside a list decoder this launch of thin strips took 0.74 instead of 0.12 ms per step).
     bool pads_known = false;
     const spiht_ctx::PadKey key = {d_coeffs, planes, ig.hs[0], ig.ws[0], wv.F, ig.L};
@@ -1204,11 +1194,6 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
         memcpy(a.hi, wv.dec_hi, sizeof(double) * Fc);
         memcpy(a.lo_f, wv.dec_lo_f, sizeof(float) * Fc);
         memcpy(a.hi_f, wv.dec_hi_f, sizeof(float) * Fc);
-        // (two levels at least: the parents of the level-1 cells are then depth-1 nodes outside the root block)
-        if (l == 1 && ig.L >= 2 && d_dmsb && cov && emit_on && !f32 && !a.color && !twopass) {
-            a.dmsb = d_dmsb;
-            spiht_dwt_d1_cover(&a, cov);
-        }
         if (twopass) {
             // smooth / antisymmetric / antireflect / periodization / long filters: two plain passes through an intermediate (dwt.hip:
             // k_dwt_axis_ext), a few planes at a time so that the intermediates stay under a gigabyte; in the pixels' precision
@@ -1417,7 +1402,7 @@ extern "C" int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t 
 }
 
 // The inverse transform in two parts, so that a pipelined caller can queue the coarse levels (a quarter of the bytes,
-// six small launches at 1080p) where no list decoder shares the GPU and only level 1 beside it (OverlappedCodec):
+// six small launches at 1080p) where no list decoder shares the GPU and only level 1 beside it (csrc/pipeline.cpp):
 //   coarse: levels level..2 -> d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] (float64), the approximation level 1 starts from
 //   level1: d_rec + d_approx -> pixels.  With fewer than two levels the coarse part does nothing and d_approx is not read.
 static int idwt_part(spiht_ctx *ctx, const int32_t *d_rec, double *d_approx, int64_t B, int64_t c, int64_t H, int64_t W,
@@ -1513,13 +1498,11 @@ static int encode_image_batch(spiht_ctx *ctx, const void *d_img_v, bool f32, int
             co = (int32_t *)ctx->coeffs.p;
         }
         CHK(ensure(ctx, ctx->maxabs, (size_t)nb * 4));
-        CHK(ensure(ctx, ctx->dmsb, (size_t)nb * g.n));  // (before the transform: level 1 writes D codes into it)
         HIPCHK(hipMemsetAsync(ctx->maxabs.p, 0, (size_t)nb * 4, ctx->stream));
-        D1Cover cov;
         CHK(dwt_forward(ctx, (const double *)((const char *)d_img + (size_t)b0 * c * H * W * esz), nb * (int)c, (int)c, ig, wavelet,
-                        mode, q_scale, d_mults, co, (uint32_t *)ctx->maxabs.p, f32, (uint8_t *)ctx->dmsb.p, &cov));
+                        mode, q_scale, d_mults, co, (uint32_t *)ctx->maxabs.p, f32));
         CHK(encode_device(ctx, g, co, nb, max_bits, d_out + (size_t)b0 * slot_stride, slot_stride, d_nbits + b0,
-                          d_max_n + b0, true, &cov));
+                          d_max_n + b0, true));
     }
     return SPIHT_OK;  // asynchronous: errors surface in spiht_ctx_synchronize()
 }
@@ -1750,12 +1733,11 @@ extern "C" int spiht_dwt_pyramid_batch_f64(spiht_ctx *ctx, const double *d_img, 
     for (int64_t b0 = 0; b0 < B; b0 += chunk) {
         int nb = (int)std::min<int64_t>(chunk, B - b0);
         int32_t *co = d_coeffs + (size_t)b0 * g.n;
-        D1Cover cov;
         CHK(dwt_forward(ctx, d_img + (size_t)b0 * c * H * W, nb * (int)c, (int)c, ig, wavelet, mode, q_scale, d_mults, co,
-                        d_maxabs + b0, false, d_dmsb ? d_dmsb + (size_t)b0 * g.n : nullptr, &cov));
+                        d_maxabs + b0, false));
         if (!d_dmsb) continue;  // transform + max|coefficient| only: the pyramid is queued elsewhere (spiht_pyramid_batch_i32)
         StageTimer t(ctx, ST_PYRAMID);
-        LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, &cov, ctx->stream));
+        LAUNCHCHK(spiht_launch_pyramid(&g, nb, co, d_dmsb + (size_t)b0 * g.n, d_lmsb + (size_t)b0 * g.n, ctx->stream));
     }
     return SPIHT_OK;
 }
@@ -1851,7 +1833,7 @@ extern "C" int spiht_unscatter_lists_batch_i32(spiht_ctx *ctx, int32_t *d_out, i
 
 // Width of the list decoder's workgroups on this context.  12 wavefronts (default) walk one stream fastest; 8 take 4 %
 // longer alone but leave the HBM-bound kernels that share the CUs with the decoder more room -- the setting of the
-// list-coding contexts of the pipelined schedule (spiht_amd/batch.py: OverlappedCodec).  Same output either way.
+// list-coding contexts of the pipelined schedule (csrc/pipeline.cpp).  Same output either way.
 // The context's mutex for a SEQUENCE of calls (it is recursive: the calls inside take it again).  What needs it: a
 // setting that is state of the context and must hold for exactly the calls of one caller -- the colour model
 // (spiht_ctx_set_color3 ... image calls ... clear): without it another thread's call on the same context could run
@@ -1867,16 +1849,13 @@ extern "C" int spiht_ctx_unlock(spiht_ctx *ctx) {
     return SPIHT_OK;
 }
 
-// Switches of this library's own making (nothing of the reference): "d1_emit" (default 0) level 1 of the forward
-// transform writes significance-pyramid codes ahead of the pyramid pass (measured, not the default);
-// "l1_flags" (default 1) the list decoder flags the occupied level-1 tiles for the inverse transform of the image-level
+// Switches of this library's own making (nothing of the reference): "l1_flags" (default 1) the list decoder flags the occupied level-1 tiles for the inverse transform of the image-level
 // decode calls.  Results are the same bits whatever the setting.  Unknown name / value: SPIHT_ERR_ARG.
 extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name || value < 0) return SPIHT_ERR_ARG;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const bool b01 = value == 0 || value == 1;
-    if (!strcmp(name, "d1_emit") && b01) ctx->opt_d1_emit = value != 0;
-    else if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
+    if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
     else if (!strcmp(name, "idwt_groups") && value <= 8) ctx->tilectr.wg_per_cu = (int32_t)value;
     else if (!strcmp(name, "wide_encode") && value <= 2) ctx->opt_wide_encode = (int)value;
     else if (!strcmp(name, "wide_groups") && value <= 256) ctx->opt_wide_g = (int)value;

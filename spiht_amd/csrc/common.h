@@ -153,44 +153,6 @@ struct MetaArgs {
     const uint32_t *spos;     // record position, sorted by (node index, position)
 };
 
-// Which depth-1 nodes (nodes whose offspring have no offspring) already have their D code when the pyramid pass
-// starts: level 1 of the forward transform writes the code of every 2x2 block of quantised detail coefficients that
-// one of its wavefronts holds whole (dwt.hip: dwt_tile<.., EMIT>) -- a wavefront computes D1_ROWS consecutive rows of
-// D1_COLS output positions of the three detail bands, so: blocks inside one band whose two rows fall into one group of
-// D1_ROWS band rows and whose two columns into one group of D1_COLS band columns.  The pyramid pass (k_pyr_12<true>)
-// then reads that byte instead of the block's four coefficients and computes only the other blocks from the array
-// itself.  Both sides evaluate the rule from these numbers (d1_rows_covered / d1_cols_covered).
-#define D1_ROWS 3
-#define D1_COLS 64
-struct D1Cover {
-    int32_t on;               // 0: nothing was written ahead (k_pyr_12<false>)
-    int32_t off_h, off_w;     // offsets of the level-1 detail bands in the packed array
-    int32_t lim_h, lim_w;     // band rows / columns written by the tile kernel itself (the rest: k_dwt_edge)
-    int32_t pad;
-};
-
-#ifdef __HIPCC__
-// Rows 2r, 2r+1 of the packed array: 1 = two rows of 'ad' held by one wavefront, 2 = of 'da' / 'dd', 0 = neither.
-__device__ __forceinline__ int d1_rows_covered(const D1Cover &v, uint32_t r) {
-    const int R = 2 * (int)r;
-    int oh, cls;
-    if (R + 1 < v.lim_h) { oh = R; cls = 1; }
-    else if (R >= v.off_h && R + 1 - v.off_h < v.lim_h) { oh = R - v.off_h; cls = 2; }
-    else return 0;
-    return (uint32_t)oh % D1_ROWS != D1_ROWS - 1 ? cls : 0;
-}
-// Columns 2c .. 2c+3 (the blocks of the two nodes c, c+1): 1 = four columns of 'da', 2 = of 'ad' / 'dd', 0 = neither.
-// A node's block is then in a level-1 band iff rows and columns are non-zero and not both 1 (1 and 1 is the approximation
-// side of the array: off_h >= band height, off_w >= band width).  Blocks whose two columns lie in two tiles (band column
-// = D1_COLS - 1 mod D1_COLS) are not told apart here: the pyramid pass writes those first (k_pyr_bcols).
-__device__ __forceinline__ int d1_cols4_in_band(const D1Cover &v, uint32_t c) {
-    const int C0 = 2 * (int)c;
-    if (C0 + 3 < v.lim_w) return 1;
-    if (C0 >= v.off_w && C0 + 3 - v.off_w < v.lim_w) return 2;
-    return 0;
-}
-#endif
-
 struct PyrArgs {
     Geom g;
     int32_t B;
@@ -198,7 +160,6 @@ struct PyrArgs {
     const int32_t *x;
     uint8_t *dmsb, *lmsb;
     uint32_t *maxabs;
-    D1Cover cov;
 };
 
 // Colour model change fused into level 1 of the transform (dwt.hip): per pixel w = M * spow(A * u, p), spow(x, p) =
@@ -223,8 +184,6 @@ struct DwtKArgs {
     int32_t *coeffs;       // [planes, enc_h, enc_w]
     const double *mults;   // device [c] or null
     uint32_t *maxabs;      // device [B] or null: atomicMax of |quantised coefficient| per image
-    uint8_t *dmsb;         // device [planes, enc_h, enc_w] or null: level 1 writes the D codes of the depth-1 nodes whose
-                           // 2x2 block lies inside one tile and one band (D1Cover; the pyramid pass computes the rest)
     double q;
     double lo[SPIHT_MAX_TAPS], hi[SPIHT_MAX_TAPS];  // dec_lo, dec_hi
     float lo_f[SPIHT_MAX_TAPS], hi_f[SPIHT_MAX_TAPS];  // ... as PyWavelets' single-precision transform has them (f32 levels)

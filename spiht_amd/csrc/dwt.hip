@@ -56,30 +56,21 @@ __device__ __forceinline__ void xcd_tile(uint32_t gx, uint32_t gy, uint32_t gz, 
 // memory line are served one after the other (11.5 ns each, measured: with one atomic per wavefront a 16-image launch
 // of level 1 took 1.6 ms for its 141 000 atomics, six times what its bytes take, and 256 images were as much
 // atomic-bound as HBM-bound).  So: one atomic per workgroup (the wavefronts meet in an LDS word first), and none when
-// the word already holds as much (MAXLOOK: 0 no look, 1 a cached load, 2 a load the atomics' coherence point answers;
-// a stale answer only costs a spare atomic).  `s_m` must have been zeroed before an earlier barrier.
-// MAXLOOK 1 relies on this: the word is only ever RAISED between two zero-fills (hipMemsetAsync in front of every
+// the word already holds as much (a cached look; measured against no look and a look the atomics' coherence point answers,
+// DESIGN.md 6; a stale answer only costs a spare atomic).  `s_m` must have been zeroed before an earlier barrier.
+// The cached look relies on this: the word is only ever RAISED between two zero-fills (hipMemsetAsync in front of every
 // transform, api.cpp), and a zero-fill is a kernel / copy of its own on the same stream -- the caches that could hold the
 // word (the CU's vector L1, and the per-XCD L2 for lines another XCD wrote) are invalidated at the kernel boundary in
 // front of this launch, so a look can return an OLD value of this launch's epoch (lower: a spare atomic) but never one
 // from before the zero-fill (higher: a lost maximum).  tests/test_gpu_dwt.py::test_maxabs_small_batch_after_large_batch
 // runs exactly the case that would show it: large magnitudes, then small ones, same context and buffer.
-#ifndef MAXLOOK
-#define MAXLOOK 1
-#endif
 __device__ __forceinline__ void block_raise_max(uint32_t *p, uint32_t v, uint32_t *s_m) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
     if ((threadIdx.x & 63) == 0 && v) atomicMax(s_m, v);
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t m = *s_m;
-#if MAXLOOK == 0
-        if (m) atomicMax(p, m);
-#elif MAXLOOK == 1
         if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) atomicMax(p, m);
-#else
-        if (m > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, m);
-#endif
     }
 }
 
@@ -138,19 +129,9 @@ __device__ __forceinline__ double dequant(int32_t r, double m, double q, bool ha
 // a zero tap contributes exactly nothing (0*x added to the running sum), so skipping it changes no bit and
 // removes a third (bior2.2) to a fifth of the float64 arithmetic.
 // One tile of k_dwt_level.
-// EMIT: the tile also writes the significance-pyramid code D(p) = 1 + msb of max|x| over the 2x2 block of cells
-// (2i..2i+1, 2j..2j+1) of the packed array (encoder_decoder.rs:66-74, :78-99: the offspring of p = (i, j)) for every such
-// block a wavefront holds whole -- the quantised values are at hand here, the pyramid pass (pyramid.hip: k_pyr_12<true>)
-// would otherwise read them back from memory.  No barrier, no LDS: a wavefront computes D1_ROWS = 3 consecutive output rows
-// (one per trip of the position loop) at 64 columns, so a thread holds both rows of one block row per band in
-// registers; the position of the top bit of a maximum is that of the OR, so the four magnitudes are ORed -- two in
-// the thread, the neighbour column's by one cross-lane read -- and the lane of the block's first column stores the
-// byte.  Blocks whose rows lie in two wavefronts' groups or whose columns in two tiles are left to the pyramid pass,
-// which evaluates the same rule (common.h: d1_rows_covered / d1_cols_covered).  (A form that folded EVERY block of the
-// tile through LDS behind the barrier of the max|coefficient| reduction cost the kernel 9 %: 4.34 instead of 3.99 ms.)
-template <int F, uint32_t LOM, uint32_t HIM, int PS, int NR, bool EMIT>
-__device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS], double (&s_hi)[2][PS], int (&s_row)[NR],
-                                         uint32_t tbx, uint32_t tby, uint32_t tbz) {
+template <int F, uint32_t LOM, uint32_t HIM, int PS, int NR>
+__device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS], double (&s_hi)[2][PS], uint32_t tbx, uint32_t tby,
+                                         uint32_t tbz) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
     constexpr int HC = (NC + 1) / 2;       // columns per parity plane
     static_assert(NC <= DW_BLOCK, "one thread per input column");
@@ -163,16 +144,12 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
 
     // input row needed for output row o, tap j: 2*o + 1 - j ; first needed row r0 = 2*oh0 + 1 - (F-1)
     const int r0 = 2 * oh0 + 2 - F, c0 = 2 * ow0 + 2 - F;
-#ifndef DWT_SCALAR_ROWS
     // the rows' element offsets (row index * in_w; -1: a row of zeros), worked out once per tile by NR threads
     __shared__ long long s_off[NR];
     if (tid < NR) {
         const int gr = ext_index(r0 + tid, a.in_h, a.mode);
         s_off[tid] = gr < 0 ? -1ll : (long long)gr * a.in_w;
     }
-#else
-    if (tid < NR) s_row[tid] = ext_index(r0 + tid, a.in_h, a.mode);
-#endif
     __shared__ uint32_t s_amax;
     if (tid == 0) s_amax = 0;
     __syncthreads();
@@ -181,7 +158,6 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     if (tid < NC) {
         const int gc = ext_index(c0 + tid, a.in_w, a.mode);
         double x[NR];
-#ifndef DWT_SCALAR_ROWS
         // Nothing of the address arithmetic on the scalar unit: a list-coding workgroup on the same CU keeps that unit busy
         // (its sequencer wavefront issues a dependent scalar instruction whenever it can, and it is the older wavefront),
         // and 28 rows x a dozen scalar instructions per tile were what this kernel lost beside it (DESIGN.md 6, round 3:
@@ -201,13 +177,6 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
                 x[r] = ok ? v : 0.0;
             }
         }
-#else
-#pragma unroll
-        for (int r = 0; r < NR; r++) {
-            const int gr = s_row[r];
-            x[r] = (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
-        }
-#endif
         const int par = tid & 1, hc = tid >> 1;
 #pragma unroll
         for (int o = 0; o < DW_TH; o++) {
@@ -232,16 +201,11 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
     uint32_t amax = 0;
     constexpr int NU = (DW_TH * DW_TW + DW_BLOCK - 1) / DW_BLOCK;  // output positions per thread
-    static_assert(!EMIT || (DW_TW == D1_COLS && DW_TW == 64 && NU == D1_ROWS && D1_ROWS == 3 && DW_TH == D1_ROWS * (DW_BLOCK / 64)),
-                  "a wavefront = D1_ROWS rows of D1_COLS output positions");
-    uint32_t mag[NU][3];  // EMIT: |quantised 'ad', 'da', 'dd'| of this thread's positions (0 outside the bands)
 #pragma unroll
     for (int u = 0; u < NU; u++) {
         const int p = tid + u * DW_BLOCK;
-        // EMIT: wavefront w takes rows 3w .. 3w+2 instead of w, w+4, w+8 (same access pattern: a wavefront = one row)
-        const int o = EMIT ? (tid >> 6) * NU + u : p / DW_TW, wcol = p % DW_TW;
+        const int o = p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
-        if (EMIT) { mag[u][0] = 0; mag[u][1] = 0; mag[u][2] = 0; }
         if (o >= DW_TH || oh >= a.out_h || ow >= a.out_w) continue;
         // x~ index 2*ow+1-j  ->  tile column 2*wcol + F-1-j  ->  parity (F-1-j)&1, half-column wcol + (F-1-j)/2
         double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
@@ -253,7 +217,6 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
             if ((HIM >> j) & 1u) { ad += a.hi[j] * vl; dd += a.hi[j] * vh; }
         }
         const int32_t qad = quant(ad, mk, a.q, has_m), qda = quant(da, mk, a.q, has_m), qdd = quant(dd, mk, a.q, has_m);
-        if (EMIT) { mag[u][0] = iabs_u(qad); mag[u][1] = iabs_u(qda); mag[u][2] = iabs_u(qdd); }
         // the few outputs of the bottom / right overhang whose sum depends on PyWavelets' tap order are computed again
         // by k_dwt_edge, which overwrites them and accounts for their magnitude
         const bool mine = oh < a.ov_h && ow < a.ov_w;
@@ -269,30 +232,12 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
         co[(size_t)(a.off_h + oh) * a.enc_w + a.off_w + ow] = qdd;     // 'dd' bottom-right
         if (mine) amax = max(amax, max(iabs_u(qad), max(iabs_u(qda), iabs_u(qdd))));
     }
-    if (EMIT) {
-        // A band's cells sit at array rows R_b + oh, columns C_b + ow, and the block of a node starts at even array
-        // coordinates (the tile origin is even): of this wavefront's rows 3w, 3w+1, 3w+2 the block row starts at the one
-        // with the parity of R_b, of the columns at those with the parity of C_b.  It must end inside what this kernel
-        // wrote of the band (lim: not the rows / columns k_dwt_edge computes again).
-        const int wv = tid >> 6, wcol = tid & 63;
-        const int lim_h = min(a.out_h, a.ov_h), lim_w = min(a.out_w, a.ov_w);
-        uint8_t *__restrict__ dm = a.dmsb + (size_t)plane * a.enc_h * a.enc_w;
-#pragma unroll
-        for (int b = 0; b < 3; b++) {
-            const int Rb = b == 0 ? 0 : a.off_h, Cb = b == 1 ? 0 : a.off_w;  // 0: 'ad', 1: 'da', 2: 'dd'
-            const int u0 = (wv * NU + Rb) & 1, o0 = wv * NU + u0;
-            uint32_t v = u0 ? (mag[1][b] | mag[2][b]) : (mag[0][b] | mag[1][b]);
-            v |= (uint32_t)__shfl_down((int)v, 1);  // the column to the right (all lanes take part)
-            if ((wcol & 1) == (Cb & 1) && wcol + 1 < DW_TW && oh0 + o0 + 1 < lim_h && ow0 + wcol + 1 < lim_w)
-                dm[(size_t)((Rb + oh0 + o0) >> 1) * a.enc_w + ((Cb + ow0 + wcol) >> 1)] = (uint8_t)(v ? 32u - (uint32_t)__clz((int)v) : 0u);
-        }
-    }
     if (a.maxabs != nullptr) {
         block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
     }
 }
 
-template <int F, uint32_t LOM, uint32_t HIM, bool EMIT = false>
+template <int F, uint32_t LOM, uint32_t HIM>
 __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
     // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
@@ -300,21 +245,13 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int RS = HC + 1, PS = DW_TH * RS + (24 - (DW_TH * RS) % 16) % 16;  // PS % 16 == 8
     __shared__ double s_lo[2][PS];
     __shared__ double s_hi[2][PS];
-    __shared__ int s_row[NR];
-#ifdef DWT_PRIO  // experiment: wave priority of the streaming kernels over whatever shares the CU with them
-    __builtin_amdgcn_s_setprio(DWT_PRIO);
-#endif
     uint32_t tbx, tby, tbz;
-#ifndef DWT_SCALAR_SETUP
     // the tile's coordinates worked out in vector registers (every lane the same values): the two divisions and everything
     // that follows from them -- plane, origin, the base pointers -- then cost the scalar unit nothing (see dwt_tile)
     uint32_t lin = blockIdx.x;
     asm volatile("" : "+v"(lin));
     xcd_tile_at(lin, (a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
-#else
-    xcd_tile((a.out_w + DW_TW - 1) / DW_TW, (a.out_h + DW_TH - 1) / DW_TH, a.planes, tbx, tby, tbz);
-#endif
-    dwt_tile<F, LOM, HIM, PS, NR, EMIT>(a, s_lo, s_hi, s_row, tbx, tby, tbz);
+    dwt_tile<F, LOM, HIM, PS, NR>(a, s_lo, s_hi, tbx, tby, tbz);
 }
 
 // ---- helpers of the persistent inverse-transform kernel (k_idwt_level_pf) -------------------------------------------
@@ -540,111 +477,6 @@ __global__ __launch_bounds__(DW_BLOCK) void k_dwt_level_f32(DwtKArgs a) {
     }
 }
 
-#ifdef SPIHT_DIAG  // experiment kept for reference (equal at best), not in the product build
-// ---- row-marching variant of the forward level ------------------------------------------------------------------
-// A workgroup owns a strip of MW_SW output columns and marches down MW_ROWS output rows: thread = input column keeps
-// the F rows its column filter needs in registers (two new rows per step, prefetched MW_PF steps ahead, so every
-// input sample is loaded exactly once per strip), the low/high outputs of the step go through a double-buffered LDS
-// row to the axis -1 filter: threads 0..127 produce (aa, ad) from the low row, threads 128..255 (da, dd) from the
-// high row.  One barrier per output row; loads are a continuous stream with no vertical halo.
-#define MW_PF 8      // steps of look-ahead for the two rows a step loads
-#define MW_ROWS 136  // output rows per workgroup
-template <int F, uint32_t LOM, uint32_t HIM>
-__global__ __launch_bounds__(256) void k_dwt_march(DwtKArgs a, uint32_t gx, uint32_t gy) {
-    constexpr int SW = (256 - (F - 2)) / 2;  // output columns per strip: exactly 256 input columns
-    constexpr int HC = 128 + 2;
-    __shared__ double s_lo[2][2][HC];        // [step parity][column parity][column >> 1]
-    __shared__ double s_hi[2][2][HC];
-    __shared__ uint32_t s_amax;
-    if (threadIdx.x == 0) s_amax = 0;  // (the barriers of the row loop come before its use)
-    uint32_t tbx, tby, tbz;
-    xcd_tile(gx, gy, a.planes, tbx, tby, tbz);
-    const int plane = (int)tbz;
-    const int ow0 = (int)tbx * SW, oa = (int)tby * MW_ROWS;
-    const int ob = min(oa + MW_ROWS, a.out_h);
-    const double *__restrict__ in = a.in + (size_t)plane * a.in_h * a.in_w;
-    const int tid = threadIdx.x;
-    const int gc = ext_index(2 * ow0 + 2 - F + tid, a.in_w, a.mode);
-    auto ld = [&](int r) -> double {
-        const int gr = ext_index(r, a.in_h, a.mode);
-        return (gc < 0 || gr < 0) ? 0.0 : in[(size_t)gr * a.in_w + gc];
-    };
-    // window: rows 2o+2-F .. 2o+1 of output row o
-    double win[F];
-#pragma unroll
-    for (int t = 0; t < F; t++) win[t] = ld(2 * oa + 2 - F + t);
-    double pq[MW_PF][2];
-#pragma unroll
-    for (int u = 0; u < MW_PF; u++) { pq[u][0] = ld(2 * (oa + 1 + u)); pq[u][1] = ld(2 * (oa + 1 + u) + 1); }
-
-    const int k = plane % a.c;
-    const bool has_m = a.mults != nullptr;
-    const double mk = has_m ? a.mults[k] : 1.0;
-    int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
-    double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
-    const int role = tid >> 7, wcol = tid & 127;
-    const int ow = ow0 + wcol;
-    const bool wr = wcol < SW && ow < a.out_w;
-    uint32_t amax = 0;
-    const int par = tid & 1, hc = tid >> 1;
-
-    for (int o0 = oa; o0 < ob; o0 += MW_PF) {
-#pragma unroll
-        for (int u = 0; u < MW_PF; u++) {
-            const int o = o0 + u;
-            // ---- axis -2 for output row o ----
-            double sl = 0.0, shh = 0.0;
-#pragma unroll
-            for (int j = 0; j < F; j++) {
-                if ((LOM >> j) & 1u) sl += a.lo[j] * win[F - 1 - j];
-                if ((HIM >> j) & 1u) shh += a.hi[j] * win[F - 1 - j];
-            }
-            s_lo[u & 1][par][hc] = sl;
-            s_hi[u & 1][par][hc] = shh;
-            // slide the window and refill the look-ahead slot
-#pragma unroll
-            for (int t = 0; t < F - 2; t++) win[t] = win[t + 2];
-            win[F - 2] = pq[u][0];
-            win[F - 1] = pq[u][1];
-            pq[u][0] = ld(2 * (o + 1 + MW_PF));
-            pq[u][1] = ld(2 * (o + 1 + MW_PF) + 1);
-            __syncthreads();
-            // ---- axis -1: two sub-bands per thread ----
-            if (wr && o < ob) {
-                const double(*src)[HC] = role ? s_hi[u & 1] : s_lo[u & 1];
-                double r0 = 0.0, r1 = 0.0;  // role 0: aa, ad   role 1: da, dd
-#pragma unroll
-                for (int j = 0; j < F; j++) {
-                    const double v = src[(F - 1 - j) & 1][wcol + ((F - 1 - j) >> 1)];
-                    if ((LOM >> j) & 1u) r0 += a.lo[j] * v;
-                    if ((HIM >> j) & 1u) r1 += a.hi[j] * v;
-                }
-                const int32_t q1 = quant(r1, mk, a.q, has_m);
-                amax = max(amax, iabs_u(q1));
-                if (role == 0) {
-                    if (a.last) {
-                        const int32_t q0 = quant(r0, mk, a.q, has_m);
-                        co[(size_t)o * a.enc_w + ow] = q0;
-                        amax = max(amax, iabs_u(q0));
-                    } else {
-                        llo[(size_t)o * a.out_w + ow] = r0;
-                    }
-                    co[(size_t)o * a.enc_w + a.off_w + ow] = q1;                      // 'ad' top-right
-                } else {
-                    const int32_t q0 = quant(r0, mk, a.q, has_m);
-                    amax = max(amax, iabs_u(q0));
-                    co[(size_t)(a.off_h + o) * a.enc_w + ow] = q0;                     // 'da' bottom-left
-                    co[(size_t)(a.off_h + o) * a.enc_w + a.off_w + ow] = q1;           // 'dd' bottom-right
-                }
-            }
-        }
-    }
-    if (a.maxabs != nullptr) {
-        block_raise_max(&a.maxabs[plane / a.c], amax, &s_amax);
-    }
-}
-#endif  // SPIHT_DIAG
-
 // ---- colour ---------------------------------------------------------------------------------------------------------
 #define SPOW_FN __device__ __forceinline__
 #define SPOW_FMA(a, b, c) fma((a), (b), (c))
@@ -663,8 +495,9 @@ __device__ __forceinline__ void spow_lds_fill(SpowLds &t, int tid) {  // needs a
 }
 
 // One pixel of the colour model change.  Shared by the stand-alone kernel (k_color3) and the fused level-1 kernels, and
-// this file is compiled without multiply-add contraction: the three produce the same bits -- and so does the CPU twin
-// oracle/color_oracle.c, which includes the same spow.h.  numpy's dot order.
+// this file is compiled without multiply-add contraction: the three produce the same bits.  (The CPU checker,
+// oracle/color_oracle.c, is an arithmetic of its own with the C library's pow(): the device is held to it within a
+// tolerance, tests/test_gpu_image.py.)  numpy's dot order.
 __device__ __forceinline__ void color3_px(const Color3 &c, const SpowLds &t, double u0, double u1, double u2, double &w0,
                                           double &w1, double &w2) {
     double v[3];
@@ -1230,9 +1063,6 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
     constexpr int KW = IW_TW / 2 + HF - 1;   // band cols staged
     constexpr int KHH = IW_TH / 4 + HF - 1;  // band rows one half-tile walks
     __shared__ double s_b[4][KH][KW + 1];    // aa, ad, da, dd (dequantised)
-#ifdef IDWT_PRIO
-    __builtin_amdgcn_s_setprio(IDWT_PRIO);
-#endif
     uint32_t tbx, tby, tbz;
     xcd_tile((a.out_w + IW_TW - 1) / IW_TW, (a.out_h + IW_TH - 1) / IW_TH, a.planes, tbx, tby, tbz);
     const int plane = (int)tbz;
@@ -1255,16 +1085,9 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
         const int bi = kh0 + r, bj = kw0 + cidx;
         double vaa = 0.0, vad = 0.0, vda = 0.0, vdd = 0.0;
         if (bi < a.band_h && bj < a.band_w) {
-#ifdef IDWT_EXP_SKIP  // timing experiment only (wrong results): what the inverse transform costs without its detail-band reads
-            const bool skp = a.band_h > IDWT_EXP_SKIP;
-            const int32_t rad = skp ? 0 : rec[(size_t)bi * a.enc_w + a.off_w + bj];
-            const int32_t rda = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + bj];
-            const int32_t rdd = skp ? 0 : rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj];
-#else
             const int32_t rad = occupied ? rec[(size_t)bi * a.enc_w + a.off_w + bj] : 0;
             const int32_t rda = occupied ? rec[(size_t)(a.off_h + bi) * a.enc_w + bj] : 0;
             const int32_t rdd = occupied ? rec[(size_t)(a.off_h + bi) * a.enc_w + a.off_w + bj] : 0;
-#endif
             if (a.first) {
                 const int32_t raa = rec[(size_t)bi * a.enc_w + bj];
                 vaa = (raa == 0 && zero_ok) ? 0.0 : dequant(raa, mk, a.q, has_m);
@@ -1357,28 +1180,14 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level(IdwtKArgs a) {
 #define IWP_WG 4
 #endif
 
-#ifndef IWP_PEEL
-#define IWP_PEEL 1
-#endif
-#ifndef IWP_USTORE
-#define IWP_USTORE 1
-#endif
-#ifdef IWP_WAVES  // experiment: cap the kernel's registers at what IWP_WAVES wavefronts per SIMD leave each
-#define IWP_ATTR __attribute__((amdgpu_waves_per_eu(IWP_WAVES, IWP_WAVES)))
-#else
-#define IWP_ATTR
-#endif
 // FLAGS: a.flags holds one word per tile (common.h: L1Flags); the detail bands of a tile whose word is zero are all zero
 // and are not read.  The loads stay unconditional -- a branch around them would make every later wait a wait for
 // everything -- and go through a buffer descriptor of the plane instead: an offset beyond it returns 0 without a trip
 // to memory.  The word of a tile is fetched when the tile's number becomes known, a tile of work ahead of its use.
 template <int F, uint32_t LOM, uint32_t HIM, bool FIRST, bool FLAGS = false>  // FIRST: coarsest level, the approximation comes from the packed array
-__global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr,
+__global__ __launch_bounds__(DW_BLOCK) void k_idwt_level_pf(IdwtKArgs a, uint32_t gx, uint32_t gy, uint32_t *ctr,
                                                                       TileBase cb) {
     static_assert(!(FIRST && FLAGS), "the flags are those of level 1 of a transform with two levels or more");
-#ifdef IDWT_PRIO
-    __builtin_amdgcn_s_setprio(IDWT_PRIO);
-#endif
     constexpr int HF = F / 2;
     constexpr int KH = IW_TH / 2 + HF - 1, KW = IW_TW / 2 + HF - 1, KHH = IW_TH / 4 + HF - 1;
     constexpr int NE = (KH * KW + DW_BLOCK - 1) / DW_BLOCK;  // staged elements per thread
@@ -1386,32 +1195,26 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     const int tid = threadIdx.x;
     // this workgroup's tiles: workgroups are dealt round-robin over the 8 XCDs; XCD x owns the contiguous tile range
     // [x*q + min(x, r), ...) and its workgroups (every 8th) take the tiles of that range in turn
-    const uint32_t nt = gx * gy * (uint32_t)a.planes, G = gridDim.x;
+    const uint32_t nt = gx * gy * (uint32_t)a.planes;
     const uint32_t x = blockIdx.x & 7u, q = nt >> 3, r8 = nt & 7u;
     const uint32_t base = x * q + (x < r8 ? x : r8), cnt = q + (x < r8 ? 1u : 0u);
-    const uint32_t per = (G + 7u - x) >> 3;  // workgroups of this launch on XCD x
     // Which tile next: with a fixed stride (tile k, k + per, ...) the workgroups drift apart over a few hundred tiles,
     // the tiles in flight on an XCD stop being neighbours and the halo rows two tiles share are fetched from HBM twice
     // (PMC: 40 instead of 31.6 MB read per 1080p image).  So the XCD's workgroups draw their tiles from a counter: what
     // is in flight is always one contiguous window of the range, as with one workgroup per tile.  Thread 0 draws a
     // tile two ahead (the answer travels under a whole tile of work) and passes it on through s_next.
     __shared__ uint32_t s_next[2];
-    uint32_t *const myctr = ctr ? ctr + 32u * x : nullptr;
+    uint32_t *const myctr = ctr + 32u * x;
     const uint32_t cbase = cb.v[x];
     uint32_t k, kn;  // position in the XCD's range of the tile being worked on / of the one after
-    if (myctr) {
-        if (tid == 0) {
-            s_next[0] = atomicAdd(myctr, 1u) - cbase;
-            s_next[1] = atomicAdd(myctr, 1u) - cbase;
-        }
-        __syncthreads();
-        k = __builtin_amdgcn_readfirstlane(s_next[0]);  // (workgroup-uniform; said so, the tile arithmetic stays scalar)
-        kn = __builtin_amdgcn_readfirstlane(s_next[1]);
-        __syncthreads();
-    } else {
-        k = blockIdx.x >> 3;
-        kn = k + per;
+    if (tid == 0) {
+        s_next[0] = atomicAdd(myctr, 1u) - cbase;
+        s_next[1] = atomicAdd(myctr, 1u) - cbase;
     }
+    __syncthreads();
+    k = __builtin_amdgcn_readfirstlane(s_next[0]);  // (workgroup-uniform; said so, the tile arithmetic stays scalar)
+    kn = __builtin_amdgcn_readfirstlane(s_next[1]);
+    __syncthreads();
 
     struct Stage {  // the samples of one tile on their way from memory: 15 registers per thread
         int32_t rad[NE], rda[NE], rdd[NE], raa[NE];
@@ -1479,7 +1282,7 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
         // the tile after `knext` is drawn here -- behind the wait for this tile's samples, ahead of the next tile's
         // loads -- and looked at only at the end of the tile (raw: a subtraction here would wait for the answer)
         uint32_t drawn = 0;
-        if (myctr && tid == 0) drawn = atomicAdd(myctr, 1u);
+        if (tid == 0) drawn = atomicAdd(myctr, 1u);
         request(g, base + min(knext, cnt - 1u), occ_next);  // unconditional (past the end: the last tile again, never used): a
         lds_barrier();                            // branch around loads makes every later wait a wait for all of them
         // ---- thread = (output column nn, half): as k_idwt_level ----
@@ -1489,7 +1292,6 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
 #pragma unroll
         for (int s2 = 0; s2 < HF; s2++) { wl[s2] = 0.0; wh[s2] = 0.0; }
         const int rbase = half * (IW_TH / 4);
-#if IWP_USTORE
         // Stores through a buffer descriptor of the plane: what falls outside the picture (rows past the plane's end by
         // the descriptor's range check, columns past out_w by an offset beyond it) is dropped by the hardware, so the
         // stores stand in straight-line code.  With branches around them the compiler cannot count them, and the wait
@@ -1497,9 +1299,6 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
         const uint32_t row_bytes = (uint32_t)a.out_w * 8u;
         const __amdgpu_buffer_rsrc_t orsrc = plane_rsrc(a.out + (size_t)plane * a.out_h * a.out_w, (uint32_t)a.out_h * row_bytes);
         const uint32_t voff0 = n < a.out_w ? (uint32_t)(2 * (kh0 + rbase)) * row_bytes + (uint32_t)n * 8u : BUF_OOB;
-#else
-        double *__restrict__ out = a.out + (size_t)plane * a.out_h * a.out_w;
-#endif
 #pragma unroll
         for (int rr = 0; rr < KHH; rr++) {
             const int r = rbase + rr;
@@ -1524,9 +1323,6 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
             wl[HF - 1] = tl;
             wh[HF - 1] = th;
             if (rr >= HF - 1) {
-#if !IWP_USTORE
-                const int m = 2 * (kh0 + r - (HF - 1));
-#endif
 #pragma unroll
                 for (int mp = 0; mp < 2; mp++) {
                     double sa = 0.0, sd = 0.0;
@@ -1538,16 +1334,12 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
                         if (hnz) sd += wh[s2] * a.hi[mp + F - 2 - 2 * s2];
                     }
                     const double sacc = (0.0 + sa) + sd;
-#if IWP_USTORE
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, sacc), orsrc,
                                                           voff0 + (uint32_t)(2 * (rr - (HF - 1)) + mp) * row_bytes, 0, 0);
-#else
-                    if (m + mp < a.out_h && n < a.out_w) out[(size_t)(m + mp) * a.out_w + n] = sacc;
-#endif
                 }
             }
         }
-        if (myctr && tid == 0) s_next[0] = drawn - cbase;
+        if (tid == 0) s_next[0] = drawn - cbase;
         lds_barrier();  // every wave has read the tile before the next one is written over it
     };
     // One tile ahead.  (Two ahead -- a second register set, 116 VGPRs -- leaves room for ONE such workgroup per CU beside
@@ -1562,17 +1354,15 @@ __global__ __launch_bounds__(DW_BLOCK) IWP_ATTR void k_idwt_level_pf(IdwtKArgs a
     // The first tile stands outside the loop: inside it the wait for a tile's samples can then be "all but the stores
     // issued since" on every path into the loop head (with the first trip inside, nothing follows the samples' loads on
     // the path from above, and the compiler has to make it a wait for everything -- the stores of the tile before).
-#if IWP_PEEL
     tile(g0, k, kn, occ_n);
     k = kn;
-    kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;  // (s_next[0] is written again only behind the
+    kn = __builtin_amdgcn_readfirstlane(s_next[0]);  // (s_next[0] is written again only behind the
                                                                          // next tile's first barrier)
     occ_n = occupancy(kn);
-#endif
     while (k < cnt) {
         tile(g0, k, kn, occ_n);
         k = kn;
-        kn = myctr ? __builtin_amdgcn_readfirstlane(s_next[0]) : kn + per;
+        kn = __builtin_amdgcn_readfirstlane(s_next[0]);
         occ_n = occupancy(kn);
     }
 }
@@ -1718,15 +1508,6 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
         hipLaunchKernelGGL((k_dwt1_color<F, LOM, HIM>), dim3(gx * gy * (uint32_t)(planes / 3)), dim3(256), 0, st, a, gx, gy);
         return (int)hipGetLastError();
     }
-#ifdef SPIHT_DIAG
-    static const int use_march = [] { const char *e = getenv("SPIHT_DWT_MARCH"); return e ? atoi(e) : 0; }();
-    if (use_march && !a.dmsb) {
-        constexpr int SW = (256 - (F - 2)) / 2;
-        const uint32_t gx = (uint32_t)((a.out_w + SW - 1) / SW), gy = (uint32_t)((a.out_h + MW_ROWS - 1) / MW_ROWS);
-        hipLaunchKernelGGL((k_dwt_march<F, LOM, HIM>), dim3(gx * gy * (uint32_t)planes), dim3(256), 0, st, a, gx, gy);
-        return (int)hipGetLastError();
-    }
-#endif
     // Outputs summed in PyWavelets' overhang order: those with jb = 2o+1-N >= 0 (constant-edge mode keeps ascending order).
     // Inputs shorter than the filter take the same order -- right-hand extension taps first, nearest first, then ascending
     // through the signal and on into the left-hand extension (checked against PyWavelets: tests/golden/short_pywt.npz).
@@ -1737,11 +1518,7 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     if (a.mode != 4) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
     const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
-#if DW_TH == 12  // (the code writer of option d1_emit is laid out for tiles of 12 rows; other heights: tile-size experiments)
-    if (a.dmsb) hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, true>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
-    else
-#endif
-    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM, false>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
     const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
     if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
@@ -1767,31 +1544,30 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
     }
     const uint32_t gx = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW), gy = (uint32_t)((a.out_h + IW_TH - 1) / IW_TH);
     const uint32_t nt = gx * gy * (uint32_t)planes;
-    static const int pf = [] { const char *e = getenv("SPIHT_IDWT_PF"); return e ? atoi(e) : 1; }();
     static const int num_cu = [] {
         int dev = 0, n = 256;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         return n;
     }();
-    // a level with several tiles per workgroup slot: persistent workgroups that fetch a tile ahead
-    static const uint32_t pf_min = [] { const char *e = getenv("SPIHT_IDWT_PF_MIN"); return e ? (uint32_t)atol(e) : 20000u; }();
-    if (pf && tc && num_cu >= 2 && nt >= pf_min && (uint64_t)(a.out_h + IW_TH) * a.out_w * 8u < (1ull << 31)) {  // (>= 8 workgroups: one per tile range at least)
-        const uint32_t G = (uint32_t)(num_cu * (pf > 1 ? pf : (tc->wg_per_cu > 0 ? tc->wg_per_cu : IWP_WG)));
-        static const int dyn = [] { const char *e = getenv("SPIHT_IDWT_DYN"); return e ? atoi(e) : 1; }();
+    // a level with several tiles per workgroup slot (20 000 tiles and more: at 1080p, level 1 of 10 images): persistent
+    // workgroups that fetch a tile ahead
+    constexpr uint32_t pf_min = 20000u;
+    if (tc && tc->dev && num_cu >= 2 && nt >= pf_min && (uint64_t)(a.out_h + IW_TH) * a.out_w * 8u < (1ull << 31)) {  // (>= 8 workgroups: one per tile range at least)
+        const uint32_t G = (uint32_t)(num_cu * (tc->wg_per_cu > 0 ? tc->wg_per_cu : IWP_WG));
         TileBase cb;
-        uint32_t *ctr = (tc && dyn) ? tc->dev : nullptr;
+        uint32_t *ctr = tc->dev;
         for (uint32_t x = 0; x < 8; x++) {
-            cb.v[x] = ctr ? tc->base[x] : 0u;
+            cb.v[x] = tc->base[x];
             // XCD x draws one number per tile of its range and two more per workgroup (the look-ahead past the end)
-            if (ctr) tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
+            tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
         }
         if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
         else if (a.flags && (uint64_t)a.enc_h * a.enc_w * 4u < (1ull << 31))
             hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
         else { a.flags = nullptr; hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb); }
         const hipError_t e = hipGetLastError();
-        if (e != hipSuccess && ctr) {  // the launch did not happen: counters and book-keeping start over together
+        if (e != hipSuccess) {  // the launch did not happen: counters and book-keeping start over together
             (void)hipMemsetAsync(tc->dev, 0, 8 * 32 * sizeof(uint32_t), st);
             for (uint32_t x = 0; x < 8; x++) tc->base[x] = 0;
         }
@@ -1811,18 +1587,6 @@ static int launch_idwt_F(const IdwtKArgs &a, int planes, hipStream_t st, TileCtr
     return launch_idwt_FM<F, (1u << F) - 1u, (1u << F) - 1u>(a, planes, st, tc);
 }
 
-// What a launch of level 1 with a->dmsb set writes ahead of the pyramid pass (same rule as launch_dwt_FM's ov_h / ov_w).
-extern "C" void spiht_dwt_d1_cover(const DwtKArgs *a, D1Cover *cv) {
-    int z = 0;
-    while (z < a->F && a->lo[z] == 0.0 && a->hi[z] == 0.0) z++;
-    int ov_h = a->out_h, ov_w = a->out_w;
-    if (a->mode != 4) ov_h = min(a->out_h, (a->in_h + z + 2) / 2);
-    if (a->mode != 4) ov_w = min(a->out_w, (a->in_w + z + 2) / 2);
-    cv->on = 1;
-    cv->off_h = a->off_h; cv->off_w = a->off_w;
-    cv->lim_h = ov_h; cv->lim_w = ov_w;
-    cv->pad = 0;
-}
 extern "C" int spiht_launch_dwt_level(const DwtKArgs *a, int planes, hipStream_t st) {
     switch (a->F) {
     case 2: return launch_dwt_F<2, 0x3u, 0x3u>(*a, planes, st);            // haar

@@ -1,5 +1,5 @@
-// The pipelined round-trip schedule behind the C ABI (include/spiht_hip.h: spiht_pipeline_*): what spiht_amd/batch.py's
-// OverlappedCodec queues from Python, for a caller in any language.  Written against the public entry points only.
+// The pipelined round-trip schedule behind the C ABI (include/spiht_hip.h: spiht_pipeline_*): the round trip of a sequence
+// of batches, for a caller in any language (Python: spiht_amd.batch.Pipeline).  Written against the public entry points only.
 //
 // The transform / pyramid / inverse-transform passes are HBM-bound, the list coder is latency-bound and leaves the HBM
 // idle, so consecutive batches are software-pipelined over three contexts ordered with events (the host never blocks):

@@ -143,13 +143,6 @@ __global__ __launch_bounds__(256) void k_pyr_round(PyrArgs a, uint32_t gx, uint3
 // Lane pairs exchange their byte results with one cross-lane read each and the even lane stores for both (one 4-byte
 // store per offspring row, 2-byte stores for the pair of q).  Nodes of the root block are left to k_pyr_ll.
 // 1-D grid, XCD-contiguous tile order; tiles: (ceil(cols/64), ceil(rows/4), B*c), block (64,4).
-// COVER: level 1 of the forward transform has written D of the depth-1 nodes whose block one of its wavefronts held whole
-// (a.cov), and k_pyr_bcols those whose two columns lie in two tiles: for a row of two such offspring the thread reads their
-// two code bytes instead of the 2x4 coefficients below them, and does not write them again.  Whether a ROW of offspring is
-// covered is the same for the whole wavefront (a wavefront = one q row): evaluated on the scalar side, no divergence;
-// the column side is two comparisons per lane.  A row that is not covered is computed from the coefficients as before
-// (always right: the array is final when this kernel runs).
-template <bool COVER>
 __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t gy, uint32_t gz) {
     const Geom g = a.g;
     uint32_t bx, by, bz;
@@ -185,51 +178,7 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
     const bool wq = dom && !((uint64_t)8 * qi + 1 < h && (uint64_t)8 * qj + 1 < w) && !(qi < lh && qj < lw);
     any = any || wq;
     int32_t xc[2][2] = {{0, 0}, {0, 0}}, xg[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    bool cvr[2] = {false, false};   // offspring row rr: both D codes are in memory already
-    uint32_t dcv[2][2] = {{0, 0}, {0, 0}};
-    if (COVER && any) {
-        const int cc = d1_cols4_in_band(a.cov, cj);
-        const uint32_t ci_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);  // (uniform: threadIdx.y is the wavefront)
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            // (the offspring of a covered row are two depth-1 nodes: their blocks lie inside the array and inside one band)
-            const int rc = ci_u + rr < h ? d1_rows_covered(a.cov, ci_u + rr) : 0;
-            cvr[rr] = rc != 0 && cc != 0 && !(rc == 1 && cc == 1);
-        }
-    }
-    if (COVER && any && (cvr[0] || cvr[1])) {
-        // the offspring's own values always; per offspring row either the two code bytes or the 2x4 values below it
-        const bool inb = gi + 3 < h && gj + 3 < w;
-        if (inb) {
-            const i2u c0 = *reinterpret_cast<const i2u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i2u *>(x + (size_t)(ci + 1) * w + cj);
-            xc[0][0] = c0.v[0]; xc[0][1] = c0.v[1]; xc[1][0] = c1.v[0]; xc[1][1] = c1.v[1];
-        } else {
-#pragma unroll
-            for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-                for (int q = 0; q < 2; q++) xc[rr][q] = (ci + rr < h && cj + q < w) ? x[(size_t)(ci + rr) * w + cj + q] : 0;
-        }
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            if (cvr[rr]) {
-                const b2u e = *reinterpret_cast<const b2u *>(dm + (size_t)(ci + rr) * w + cj);
-                dcv[rr][0] = e.v[0]; dcv[rr][1] = e.v[1];
-            } else if (inb) {
-#pragma unroll
-                for (int r2 = 0; r2 < 2; r2++) {
-                    const i4u r = *reinterpret_cast<const i4u *>(x + (size_t)(gi + 2 * rr + r2) * w + gj);
-#pragma unroll
-                    for (int q = 0; q < 4; q++) xg[2 * rr + r2][q] = r.v[q];
-                }
-            } else {
-#pragma unroll
-                for (int r2 = 0; r2 < 2; r2++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        xg[2 * rr + r2][q] = (gi + 2 * rr + r2 < h && gj + q < w) ? x[(size_t)(gi + 2 * rr + r2) * w + gj + q] : 0;
-            }
-        }
-    } else if (any) {
+    if (any) {
         if (gi + 3 < h && gj + 3 < w) {
             const i2u c0 = *reinterpret_cast<const i2u *>(x + (size_t)ci * w + cj), c1 = *reinterpret_cast<const i2u *>(x + (size_t)(ci + 1) * w + cj);
             i4u r[4];
@@ -261,18 +210,12 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
             uint32_t d = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) d = max(d, msb_code(iabs_u(xg[2 * rr + (u >> 1)][2 * q + (u & 1)])));
-            if (COVER && cvr[rr]) d = dcv[rr][q];
             dch[rr][q] = has ? d : 0u;
             dq = max(dq, max(msb_code(iabs_u(xc[rr][q])), dch[rr][q]));
             lq = max(lq, dch[rr][q]);
         }
     // pack: this lane's bytes | partner's bytes (lanes 2k, 2k+1 own adjacent columns)
     const uint32_t mine0 = dch[0][0] | (dch[0][1] << 8), mine1 = dch[1][0] | (dch[1][1] << 8);
-    if (COVER) {
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++)
-            if (cvr[rr]) { wr[rr][0] = false; wr[rr][1] = false; }
-    }
     const uint32_t mflags = (wr[0][0] ? 1u : 0u) | (wr[0][1] ? 2u : 0u) | (wr[1][0] ? 4u : 0u) | (wr[1][1] ? 8u : 0u) | (wq ? 16u : 0u);
     const uint32_t mineq = dq | (lq << 8) | (mflags << 16);
     const uint32_t oth0 = (uint32_t)__shfl_xor((int)mine0, 1), oth1 = (uint32_t)__shfl_xor((int)mine1, 1);
@@ -307,29 +250,6 @@ __global__ __launch_bounds__(256) void k_pyr_12(PyrArgs a, uint32_t gx, uint32_t
             if (w1) { dm[qo + 1] = (uint8_t)othq; lm[qo + 1] = (uint8_t)(othq >> 8); }
         }
     }
-}
-
-// D of the depth-1 nodes whose 2x2 block lies in one level-1 band but in two tiles of the forward transform (band column
-// D1_COLS - 1 mod D1_COLS: only bands that start at an odd array column have such blocks): the wavefronts of level 1 could
-// not fold them, and the pass above takes them as written.  Thread = (band, block row, boundary column); from the array.
-// grid: (ceil(rows * ncol / 256), 2, planes): y = 0 'ad', 1 'dd'.
-__global__ __launch_bounds__(256) void k_pyr_bcols(PyrArgs a, uint32_t ncol) {
-    const D1Cover v = a.cov;
-    const uint32_t w = (uint32_t)a.g.w;
-    const int Rb = blockIdx.y == 0 ? 0 : v.off_h, Cb = v.off_w;
-    // block rows of the band: first band row oh0 with (Rb + oh0) even, then every second one, while oh + 1 < lim_h
-    const int oh0 = Rb & 1;
-    const uint32_t nrow = v.lim_h > oh0 + 1 ? (uint32_t)(v.lim_h - oh0) / 2u : 0u;
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nrow * ncol) return;
-    const uint32_t ri = t / ncol, k = t - ri * ncol;
-    const int oh = oh0 + 2 * (int)ri, ow = D1_COLS - 1 + D1_COLS * (int)k;
-    if (oh + 1 >= v.lim_h || ow + 1 >= v.lim_w) return;
-    const uint32_t R = (uint32_t)(Rb + oh), Cc = (uint32_t)(Cb + ow);  // both even by construction
-    const int32_t *x = a.x + (size_t)blockIdx.z * a.g.hw;
-    const i2u r0 = *reinterpret_cast<const i2u *>(x + (size_t)R * w + Cc), r1 = *reinterpret_cast<const i2u *>(x + (size_t)(R + 1) * w + Cc);
-    const uint32_t m = iabs_u(r0.v[0]) | iabs_u(r0.v[1]) | iabs_u(r1.v[0]) | iabs_u(r1.v[1]);  // top bit of the max = top bit of the OR
-    a.dmsb[(size_t)blockIdx.z * a.g.hw + (size_t)(R >> 1) * w + (Cc >> 1)] = (uint8_t)msb_code(m);
 }
 
 // Root block (encoder_decoder.rs:44-63).  grid: (ceil(ll_w*ll_h/256), 1, B*c)
@@ -396,12 +316,8 @@ extern "C" int spiht_pyr_rounds(const Geom *g) {
     return best;
 }
 
-// cov: what level 1 of the forward transform wrote into d_dmsb ahead of this pass (nullptr: nothing)
-extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb,
-                                    const D1Cover *cov, hipStream_t st) {
+extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st) {
     PyrArgs a;
-    memset(&a.cov, 0, sizeof(a.cov));
-    if (cov) a.cov = *cov;
     a.g = *g;
     a.B = B;
     a.x = d_x;
@@ -415,13 +331,7 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
         if (rows && pairs) {
             const uint32_t cols = 2 * pairs;  // an even number of columns: lane pairs stay together
             const uint32_t gx = (cols + 63) / 64, gy = (rows + 3) / 4, gz = (uint32_t)(B * g->c);
-            if (a.cov.on && (a.cov.off_w & 1) && a.cov.lim_w > D1_COLS) {  // blocks that straddle two tiles of level 1
-                const uint32_t ncol = (uint32_t)(a.cov.lim_w - D1_COLS) / D1_COLS + 1u;  // ow = 63, 127, .. with ow + 1 < lim_w
-                const uint32_t nrow = (uint32_t)a.cov.lim_h / 2u + 1u;
-                hipLaunchKernelGGL(k_pyr_bcols, dim3((nrow * ncol + 255) / 256, 2, gz), dim3(256), 0, st, a, ncol);
-            }
-            if (a.cov.on) hipLaunchKernelGGL(k_pyr_12<true>, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
-            else hipLaunchKernelGGL(k_pyr_12<false>, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
+            hipLaunchKernelGGL(k_pyr_12, dim3(gx * gy * gz), dim3(64, 4), 0, st, a, gx, gy, gz);
         }
     }
     for (int d = 3; d <= rounds; d++) {

@@ -1,5 +1,5 @@
-// x^p for x > 0 in float64, shared by the colour kernels (dwt.hip) and -- the same operations in the same order, so the
-// same bits -- by their CPU twin (oracle/color_oracle.c, test infrastructure).
+// x^p for x > 0 in float64, for the colour kernels (dwt.hip).  (The CPU checker oracle/color_oracle.c does not include this
+// file: it uses the C library's pow(); tests/native/spow_probe.c measures this function against 60-digit arithmetic.)
 //
 // The colour model change (RGB <-> IPT: spiht/color_models.py:6-13 -> colour-science) takes three signed powers per
 // pixel and is arithmetic-bound: the device library's pow() costs about 250 float64 instruction slots (it carries the

@@ -232,16 +232,14 @@ D1_CASES = [(3, 96, 160, "bior2.2", "reflect", 3), (1, 97, 163, "bior2.2", "symm
 
 
 @pytest.mark.parametrize("case", D1_CASES)
-def test_pyramid_codes_written_by_forward_level1(oracle, case):
-    """Level 1 of the forward transform writes the D codes of the 2x2 coefficient blocks it holds (dwt.hip: dwt_tile<..,
-    EMIT>), the pyramid pass reads them and computes the blocks that straddle tiles or bands itself (pyramid.hip:
-    k_pyr_12<true>, common.h: d1_covered).  The result must be the recursion's (encoder_decoder.rs:78-121, evaluated
-    per node by the oracle) at every node with offspring -- and the same as the pyramid pass alone gives."""
+def test_pyramid_behind_the_forward_transform(oracle, case):
+    """spiht_dwt_pyramid_batch_f64 (the front half of the encoder as the pipelined schedule queues it): the significance
+    pyramid it leaves must be the recursion's (encoder_decoder.rs:78-121, evaluated per node by the oracle) at every node
+    with offspring -- and the same as the pyramid pass on its own gives over the same coefficients."""
     from spiht_amd import _lib
     from spiht_amd.batch import DeviceArray
     c, H, W, wavelet, mode, level = case
     L, ctx, vp = _lib.lib(), _lib.Context(0), C.c_void_p
-    ctx.set_option("d1_emit", 1)  # (not the default: DESIGN.md 6)
     wid, mid = L.spiht_wavelet_id(wavelet.encode()), L.spiht_mode_id(mode.encode())
     lv = -1 if level is None else level
     v = [C.c_int64() for _ in range(6)]

@@ -244,84 +244,6 @@ def test_raw_batch_entry_points(oracle):
     ctx.synchronize()  # the error word was cleared
 
 
-@pytest.mark.parametrize("shape", [(3, 96, 136, 5, 9000, 7), (1, 61, 47, 1, 2500, 5), (3, 130, 75, 3, None, 4),
-                                   (2, 200, 264, 9, 40000, 6)])
-def test_overlapped_codec_matches_fused(oracle, shape):
-    """split entry points + events (include/spiht_hip.h "two halves"): same streams, same images as the fused calls,
-    over several pipelined batches with different contents"""
-    from spiht_amd import _lib
-    from spiht_amd.batch import BatchCodec, DeviceArray, OverlappedCodec
-    from spiht_amd.spiht_wrapper import SpihtSettings
-    c, H, W, B, mb, steps = shape  # steps: the buffer pairs are reused -- the zeros put back after a batch are what the
-    ctx = _lib.default_context()   # next one on the same pair needs
-    codec = BatchCodec(c, H, W, SpihtSettings(), None, mb, ctx=ctx)
-    g = codec.geom
-    ov = OverlappedCodec(codec, B)
-    imgs = [np.stack([synth_image(100 * s + b, c, H, W) for b in range(B)]) for s in range(steps)]
-    d_imgs = [DeviceArray(ctx, (B, c, H, W), np.float64) for _ in range(steps)]
-    d_recs = [DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64) for _ in range(steps)]
-    # streams are single-buffered inside a pipeline; give every step its own here so all of them can be compared
-    d_outs = [DeviceArray(ctx, (B, codec.slot_stride), np.uint8) for _ in range(steps)]
-    d_nbits = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
-    d_maxn = [DeviceArray(ctx, (B,), np.uint8) for _ in range(steps)]
-    d_nbytes = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
-    for s in range(steps):
-        d_imgs[s].upload(imgs[s])
-    for s in range(steps):
-        ov.submit(d_imgs[s].ptr, d_outs[s].ptr, d_nbits[s].ptr, d_maxn[s].ptr, d_nbytes[s].ptr, d_recs[s].ptr)
-    ov.synchronize()
-    for s in range(steps):
-        res = codec.encode(imgs[s])                      # fused path
-        nb = d_nbits[s].download()
-        out = d_outs[s].download()
-        mn = d_maxn[s].download()
-        for b in range(B):
-            assert (int(nb[b]) + 7) // 8 == len(res[b].encoded_bytes) and int(mn[b]) == res[b].max_n
-            assert out[b, :len(res[b].encoded_bytes)].tobytes() == res[b].encoded_bytes
-        rec = d_recs[s].download()
-        ref = np.stack(codec.decode(res))
-        assert np.array_equal(rec[:, :, :ref.shape[2], :ref.shape[3]], ref)
-
-
-@pytest.mark.parametrize("opts", [dict(pair="forward"), dict(split_inverse=True), dict(pair="forward", split_inverse=True),
-                                  dict(u_early=False), dict(e_first=True, l_priority=1, u_early=False), dict(decoder_waves=12),
-                                  dict(coarse_first=True), dict(l1_flags=False)])
-def test_overlapped_codec_schedule_variants(opts):
-    """Every arrangement of the pipelined schedule (OverlappedCodec: what the decoder shares the GPU with, the inverse
-    transform in two parts -- spiht_idwt_coarse_batch_f64 / spiht_idwt_level1_batch_f64 --, where the unscatter goes,
-    stream priorities) codes the same streams and pictures as the fused calls, with and without a colour model."""
-    import spiht_amd
-    from spiht_amd import _lib
-    from spiht_amd.batch import BatchCodec, DeviceArray, OverlappedCodec
-    ctx = _lib.default_context()
-    for settings, (c, H, W, B, mb, steps, level) in (
-            (spiht_amd.SpihtSettings(), (3, 130, 200, 4, 20000, 5, 4)),
-            (spiht_amd.SpihtSettings(), (1, 61, 47, 3, 2500, 4, 1)),       # one level: no coarse part
-            (spiht_amd.SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0]),
-             (3, 96, 136, 3, 9000, 4, 3))):
-        codec = BatchCodec(c, H, W, settings, level, mb, ctx=ctx)
-        g = codec.geom
-        ov = OverlappedCodec(codec, B, **opts)
-        imgs = [np.stack([synth_image(700 + 10 * st + b, c, H, W) for b in range(B)]) for st in range(steps)]
-        d_imgs = [DeviceArray(ctx, (B, c, H, W), np.float64) for _ in range(steps)]
-        d_recs = [DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64) for _ in range(steps)]
-        d_outs = [DeviceArray(ctx, (B, codec.slot_stride), np.uint8) for _ in range(steps)]
-        d_nbits = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
-        d_maxn = [DeviceArray(ctx, (B,), np.uint8) for _ in range(steps)]
-        d_nbytes = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)]
-        for st in range(steps):
-            d_imgs[st].upload(imgs[st])
-        for st in range(steps):
-            ov.submit(d_imgs[st].ptr, d_outs[st].ptr, d_nbits[st].ptr, d_maxn[st].ptr, d_nbytes[st].ptr, d_recs[st].ptr)
-        ov.synchronize()
-        for st in range(steps):
-            res = codec.encode(imgs[st])
-            nb, out, mn = d_nbits[st].download(), d_outs[st].download(), d_maxn[st].download()
-            for b in range(B):
-                assert int(mn[b]) == res[b].max_n and out[b, :(int(nb[b]) + 7) // 8].tobytes() == res[b].encoded_bytes, (opts, st, b)
-            assert np.array_equal(d_recs[st].download(), np.stack(codec.decode(res))), (opts, st)
-
-
 def test_progressive_prefixes_in_one_batch(oracle):
     """make_gif.py:46-61: byte prefixes of one stream, decoded together; quality never gets worse"""
     import spiht_amd
@@ -506,13 +428,15 @@ def test_device_colour_conversion_and_config3_batch():
 @pytest.mark.gpu
 def test_config4_shard_256_distinct_1080p():
     """BASELINE config 4's per-GPU shard, as bench.py times it: 256 DISTINCT 1920x1080 RGB images (image i: seed
-    1000 + i), bior2.2 reflect level 7, 0.5 bpp, through the pipelined schedule (OverlappedCodec, two
-    consecutive batches so that both buffer sets and both list-coding contexts are used).  EVERY image's stream, max_n
-    and decoded picture is compared with the CPU oracle (one oracle round trip per image, spread over the host cores)."""
+    1000 + i), bior2.2 reflect level 7, 0.5 bpp, through the pipelined schedule bench.py times -- the library's
+    own (spiht_pipeline_submit, csrc/pipeline.cpp; spiht_amd.batch.Pipeline) --, three consecutive steps so that both buffer
+    sets and both list-coding contexts are used and the second set's output passes through the split inverse transform
+    beside the next step's decoder.  EVERY image's stream, max_n and decoded picture is compared with the CPU oracle (one
+    oracle round trip per image, spread over the host cores)."""
     import spiht_amd
     from parity_workers import digest, oracle_roundtrip_job, pool, synth_u8_job
     from spiht_amd import _lib
-    from spiht_amd.batch import BatchCodec, DeviceArray, OverlappedCodec
+    from spiht_amd.batch import BatchCodec, DeviceArray, Pipeline
     B = int(os.environ.get("SPIHT_TEST_SHARD", "256"))
     c, H, W, level = 3, 1080, 1920, 7
     mb = int(H * W * 0.5)
@@ -525,12 +449,11 @@ def test_config4_shard_256_distinct_1080p():
     with pool() as ex:
         for b, u8 in enumerate(ex.map(synth_u8_job, [(1000 + b, c, H, W) for b in range(B)])):
             d_img.upload(u8 / 255, offset_bytes=b * per)
-        d_out, d_nbits, d_maxn, d_nbytes = (DeviceArray(ctx, (B, slot), np.uint8), DeviceArray(ctx, (B,), np.uint64),
-                                            DeviceArray(ctx, (B,), np.uint8), DeviceArray(ctx, (B,), np.uint64))
+        d_out, d_nbits, d_maxn = DeviceArray(ctx, (B, slot), np.uint8), DeviceArray(ctx, (B,), np.uint64), DeviceArray(ctx, (B,), np.uint8)
         d_rec = DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64)
-        pipe = OverlappedCodec(codec, B)
-        for _ in range(3):  # batches 1 and 2 leave through different buffer sets; the last one is what is compared
-            pipe.submit(d_img.ptr, d_out.ptr, d_nbits.ptr, d_maxn.ptr, d_nbytes.ptr, d_rec.ptr)
+        pipe = Pipeline(codec, B)
+        for _ in range(3):  # steps 1 and 2 leave through different buffer sets; the last one is what is compared
+            pipe.submit(d_img.ptr, d_out.ptr, d_nbits.ptr, d_maxn.ptr, d_rec.ptr)
         pipe.synchronize()
         nbits, maxn, streams = d_nbits.download(), d_maxn.download(), d_out.download()
         assert (nbits == mb).all()
@@ -541,6 +464,7 @@ def test_config4_shard_256_distinct_1080p():
             ctx.download(rec1, d_rec.ptr + b * c * g["rec_h"] * g["rec_w"] * 8)
             if streams[b, :mb // 8].tobytes() != data or int(maxn[b]) != mn or digest(rec1) != dg:
                 bad.append(b)
+    pipe.close()
     assert not bad, "images that differ from the oracle: %s" % bad[:16]
 
 
@@ -689,7 +613,8 @@ def test_colour_model_is_per_caller_across_threads(oracle):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cfg", [(3, 96, 136, 5, 9000, 7, None, False), (1, 61, 47, 2, 2500, 4, 1, False), (3, 130, 200, 3, None, 4, 4, False),
-                                 (3, 96, 136, 3, 9000, 4, 3, True)])
+                                 (3, 96, 136, 3, 9000, 4, 3, True), (2, 200, 264, 9, 40000, 6, None, False), (3, 130, 75, 3, None, 4, None, False),
+                                 (1, 61, 47, 1, 2500, 5, None, False)])
 def test_c_pipeline_matches_fused(cfg):
     """include/spiht_hip.h spiht_pipeline_*: the pipelined schedule queued by the library itself (csrc/pipeline.cpp) codes the
     same streams and pictures as the fused calls -- several steps with different contents through both buffer sets, one
