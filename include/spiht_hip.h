@@ -268,12 +268,20 @@ int spiht_dequant_idwt_flags_batch_f64(spiht_ctx *ctx, const int32_t *d_rec, con
  * "wide_encode" (default 1): an encode call of few images (at most half as many as the device has CUs, each of 2^18
  * coefficients or more) codes each image on a group of workgroups, one per CU, instead of one workgroup -- the latency of a
  * single call (csrc/encode_wide.hip); 0: always one workgroup per image; 2: groups whatever the size of the image
- * (tests).  "wide_groups" (default 0 = by image size, 2 ... 64): workgroups per image of that path, 0 ... 256;
- * "wide_solo" (default 24576): list entries up to which a bit plane is still coded by the group's first workgroup alone.  Such
- * launches are queued one at a time per device (their workgroups wait for one another and must all be resident).
+ * (tests); 3: as 2, and every group finds itself "given up" (tests of the fallback below).  "wide_groups" (default 0 = by
+ * image size, 2 ... 64): workgroups per image of that path, 0 ... 256; "wide_solo" (default 24576): list entries up to
+ * which a bit plane is still coded by the group's first workgroup alone.  The workgroups of a group wait for one another
+ * and should all be resident: the library keeps a launch within what the device holds of that kernel and queues such
+ * launches of one process one at a time per device; when other work holds the CUs all the same (another process, a long
+ * kernel of the caller's), a group gives up after a bounded wait (tens of milliseconds) and the image is coded by one
+ * workgroup instead, queued behind on the same stream -- same bits, never an error (spiht_ctx_wide_stats tells).
  * "idwt_groups" (default 0 = 4): persistent workgroups per CU of the large inverse-transform levels; 3 leaves a list
- * decoder's workgroup room beside them (the pipelined schedule sets it). */
+ * decoder's workgroup room beside them (the pipelined schedule sets it around its own calls). */
 int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t value);
+int spiht_ctx_get_option(spiht_ctx *ctx, const char *name, int64_t *value);
+/* The last encode call of this context that took the several-CUs-per-image path: its images (groups) and how many of them
+ * gave up for lack of residency and were coded by the single-workgroup kernel instead.  Waits for the context's stream. */
+int spiht_ctx_wide_stats(spiht_ctx *ctx, uint32_t *groups, uint32_t *gave_up);
 
 /* The inverse transform (spiht_dequant_idwt_batch_f64) in two parts, for the same kind of schedule: the coarse levels
  * (level .. 2: a quarter of the bytes) into d_approx [B*c, 2*hs[2]-F+2, 2*ws[2]-F+2] float64 -- the approximation level 1
@@ -305,6 +313,9 @@ int spiht_color3_batch_f64(spiht_ctx *ctx, const double *d_in, double *d_out, in
  * the plain transform.  A_f == NULL clears the setting.  Images with other channel counts are coded as they are. */
 int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const double *M_f, double p_f, const double *A_i,
                          const double *M_i, double p_i);
+/* ... and what is set at the moment (*on == 0: nothing, the arrays are left alone; output pointers other than `on` may be
+ * NULL) -- for code that borrows a context and puts the caller's setting back (csrc/pipeline.cpp). */
+int spiht_ctx_get_color3(spiht_ctx *ctx, int *on, double *A_f, double *M_f, double *p_f, double *A_i, double *M_i, double *p_i);
 
 /* Progressive decoding of one stream to K bit budgets from ONE walk (the reference decodes a prefix per frame,
  * make_gif.py:46-61: `decode(original_bytes[:byte_len], ...)`, i.e. K walks).  budgets_bits: host array,
@@ -401,7 +412,7 @@ int spiht_comm_allreduce_max_f64(spiht_ctx *ctx, spiht_comm *comm, double *value
  * decoder has read them before the next step's encoder writes them).
  *   create        geometry and settings as spiht_encode_image_batch_f64; max_bits 0 = unlimited
  *   info          stream slot size in bytes (spiht_encode_bound) and the decoded picture size
- *   set_color3    colour model of the coded picture (spiht_ctx_set_color3) for every step
+ *   set_color3    colour model of the coded picture (as spiht_ctx_set_color3) for every step; kept by the pipeline
  *   submit        queue one step; the decoded pictures of step i are complete after submit of step i+1 has been followed
  *                 by _synchronize -- or after _flush + waiting
  *   submit_gather the same in a multi-GPU job: the streams are all-gathered (spiht_gather_streams) between encoder and
@@ -413,7 +424,10 @@ typedef struct spiht_pipeline spiht_pipeline;
 int spiht_pipeline_create(int device, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode, int level,
                           double q_scale, const double *channel_mults, uint64_t max_bits, spiht_pipeline **out);
 /* ... the HBM-bound passes on the caller's context h_ctx (on `device`; not destroyed with the pipeline): a process has few
- * hardware queues for its HIP streams, a caller that holds a context already should not add a fourth stream */
+ * hardware queues for its HIP streams, a caller that holds a context already should not add a fourth stream.  Nothing of
+ * the pipeline's stays on h_ctx between calls: while submit / flush queue work they hold its mutex and have the pipeline's
+ * colour model and options on it, and put back what the caller had set.  A call that fails half-way leaves the pipeline
+ * unusable: every later call returns that first error (destroy it). */
 int spiht_pipeline_create_on(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, int64_t H, int64_t W, int wavelet, int mode,
                              int level, double q_scale, const double *channel_mults, uint64_t max_bits, spiht_pipeline **out);
 void spiht_pipeline_destroy(spiht_pipeline *p);
@@ -427,6 +441,13 @@ int spiht_pipeline_synchronize(spiht_pipeline *p);
 int spiht_pipeline_contexts(spiht_pipeline *p, spiht_ctx **h, spiht_ctx **l0, spiht_ctx **l1);
 
 /* Thin device-memory helpers so a host language without a HIP binding can drive the batched API. */
+/* Page-locked host memory for the arrays the host-array calls RETURN (decode_image gives back a new array,
+ * spiht_wrapper.py:192-216): a device -> host copy into it is one DMA at the link's speed, into fresh pageable memory
+ * several times slower (page faults + staging).  Pooled inside the library (pinning is what costs); at most 4 GiB are
+ * handed out -- beyond that, or when the system refuses, SPIHT_ERR_NOMEM and the caller takes ordinary memory: every
+ * host-array call accepts any host pointer.  Not tied to a context or device. */
+int spiht_host_alloc(uint64_t bytes, void **h_ptr);
+int spiht_host_free(void *h_ptr);
 int spiht_dev_alloc(spiht_ctx *ctx, uint64_t bytes, void **d_ptr);
 int spiht_dev_free(spiht_ctx *ctx, void *d_ptr);
 int spiht_dev_upload(spiht_ctx *ctx, void *d_dst, const void *h_src, uint64_t bytes);

@@ -41,7 +41,7 @@ SYMBOLS = [
     "spiht_decode_with_metadata_i32", "spiht_encode_batch_i32", "spiht_decode_batch_i32", "spiht_wavelet_id", "spiht_mode_id", "spiht_geometry",
     "spiht_encode_image_batch_f64", "spiht_decode_image_batch_f64", "spiht_dwt_quant_batch_f64",
     "spiht_encode_image_batch_f32", "spiht_dwt_quant_batch_f32",
-    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_ctx_set_decoder_waves", "spiht_decode_budgets_i32", "spiht_decode_budgets_dev_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free",
+    "spiht_dequant_idwt_batch_f64", "spiht_pyramid_batch_i32", "spiht_color3_batch_f64", "spiht_ctx_set_color3", "spiht_ctx_get_color3", "spiht_ctx_set_decoder_waves", "spiht_decode_budgets_i32", "spiht_decode_budgets_dev_i32", "spiht_nbits_to_nbytes", "spiht_dev_alloc", "spiht_dev_free", "spiht_host_alloc", "spiht_host_free",
     "spiht_dev_upload", "spiht_dev_download", "spiht_dev_memset", "spiht_dev_copy",
     "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_level1_flags_batch_f64", "spiht_idwt_approx_shape",
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
@@ -50,7 +50,7 @@ SYMBOLS = [
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
     "spiht_pipeline_create", "spiht_pipeline_create_on", "spiht_pipeline_destroy", "spiht_pipeline_info", "spiht_pipeline_set_color3", "spiht_pipeline_submit",
     "spiht_pipeline_submit_gather", "spiht_pipeline_flush", "spiht_pipeline_synchronize", "spiht_pipeline_contexts",
-    "spiht_geometry_mode", "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
+    "spiht_geometry_mode", "spiht_wavelet_taps", "spiht_ctx_set_option", "spiht_ctx_get_option", "spiht_ctx_wide_stats", "spiht_l1_flags_words", "spiht_decode_lists_flags_batch_i32", "spiht_dequant_idwt_flags_batch_f64",
 ]
 
 
@@ -92,6 +92,7 @@ def lib():
         L.spiht_unscatter_lists_batch_i32.argtypes = [vp, vp, i64, i64, i64, i64]
         L.spiht_color3_batch_f64.argtypes = [vp, vp, vp, i64, i64, vp, vp, C.c_double]
         L.spiht_ctx_set_color3.argtypes = [vp, vp, vp, C.c_double, vp, vp, C.c_double]
+        L.spiht_ctx_get_color3.argtypes = [vp, C.POINTER(i32), vp, vp, C.POINTER(C.c_double), vp, vp, C.POINTER(C.c_double)]
         L.spiht_ctx_set_decoder_waves.argtypes = [vp, C.c_int]
         L.spiht_decode_budgets_i32.argtypes = [vp, vp, u64, C.c_uint8, i64, i64, i64, i64, i64, vp, i64, vp]
         L.spiht_decode_budgets_dev_i32.argtypes = [vp, vp, u64, C.c_uint8, i64, i64, i64, i64, i64, vp, i64, vp]
@@ -146,7 +147,11 @@ def lib():
         L.spiht_comm_allreduce_max_f64.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.spiht_rccl_library.restype = C.c_char_p
         L.spiht_rccl_library.argtypes = []
+        L.spiht_host_alloc.argtypes = [u64, C.POINTER(vp)]
+        L.spiht_host_free.argtypes = [vp]
         L.spiht_ctx_set_option.argtypes = [vp, C.c_char_p, i64]
+        L.spiht_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
+        L.spiht_ctx_wide_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.spiht_l1_flags_words.argtypes = [i64, i64, i64, i32, i32, i32, C.POINTER(u64)]
         L.spiht_decode_lists_flags_batch_i32.argtypes = [vp, vp, u64, vp, vp, i64, i64, i64, i64, i32, i32, i32, vp, vp]
         L.spiht_geometry_mode.argtypes = [i64, i64, i32, i32, i32, C.POINTER(i32)] + [C.POINTER(i64)] * 6
@@ -229,6 +234,17 @@ class Context:
         """a switch of the library (spiht_ctx_set_option): "l1_flags", "pads_persist", "wide_encode", "wide_groups",
         "wide_solo", "idwt_groups"; results do not depend on them"""
         check(self._lib.spiht_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        check(self._lib.spiht_ctx_get_option(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
+    def wide_stats(self):
+        """(images, images that fell back to the single-workgroup encoder) of the last several-CUs-per-image encode call"""
+        g, u = C.c_uint32(), C.c_uint32()
+        check(self._lib.spiht_ctx_wide_stats(self.handle, C.byref(g), C.byref(u)))
+        return int(g.value), int(u.value)
 
     def set_decoder_waves(self, waves):
         """wavefronts per decoder workgroup on this context: 12 (default, fastest alone) or 8 (lighter beside HBM-bound
@@ -313,6 +329,33 @@ class Event:
 
 _ctxs = {}
 _ctx_lock = threading.Lock()
+
+
+def _host_free(ptr):
+    try:
+        if _lib is not None:
+            _lib.spiht_host_free(C.c_void_p(ptr))
+    except Exception:  # interpreter shutdown
+        pass
+
+
+def result_array(shape, dtype):
+    """An uninitialised array for a call to fill and RETURN (the reference's decode calls return new arrays,
+    spiht_wrapper.py:192-216, lib.rs:35-42): backed by page-locked memory from the library's pool (spiht_host_alloc), so
+    the device -> host copy is one DMA at the link's speed; the buffer goes back to the pool when the array -- and every
+    view of it -- is gone.  Small arrays, or when no such memory is to be had: an ordinary numpy array."""
+    import weakref
+    import numpy as np
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < (1 << 20):
+        return np.empty(shape, dtype)
+    p = C.c_void_p()
+    if lib().spiht_host_alloc(nbytes, C.byref(p)) != OK or not p.value:
+        return np.empty(shape, dtype)
+    buf = (C.c_char * nbytes).from_address(p.value)
+    weakref.finalize(buf, _host_free, p.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
 
 def default_context(device=None):

@@ -20,6 +20,7 @@ int spiht_launch_absmax(const int32_t *d_x, int B, uint32_t n, uint32_t *d_maxab
 int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, uint8_t *d_dmsb, uint8_t *d_lmsb, hipStream_t st);
 int spiht_launch_encode(const EncArgs *a, hipStream_t st);
 int spiht_launch_encode_wide(const EncArgs *a, const WideArgs *w, int groups, hipStream_t st);
+int spiht_wide_groups_per_cu(void);
 int spiht_launch_decode(const DecArgs *a, hipStream_t st);
 int spiht_launch_decode_w8(const DecArgs *a, hipStream_t st);  // the 8-wavefront build of decode.hip
 int spiht_launch_unscatter(const DecArgs *a, hipStream_t st);
@@ -91,7 +92,7 @@ struct spiht_ctx {
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
     DevBuf tilebuf;      // tile counters of the persistent inverse-transform kernel
-    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, 0};
+    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0};
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
@@ -101,7 +102,7 @@ struct spiht_ctx {
     // spiht_ctx_set_option
     bool opt_l1_flags = true;   // the decoder flags the occupied level-1 tiles for the inverse transform
     bool opt_pads_persist = false;  // coefficient arrays this context has filled keep their zero padding (see dwt_forward)
-    struct PadKey { const void *p; int planes; int64_t H, W; int F, L; };
+    struct PadKey { const void *p; int planes; int64_t H, W; int F, L, mode; };
     std::vector<PadKey> pads_zeroed;  // arrays whose padding strips this context has zeroed (opt_pads_persist)
     DevBuf l1flags;             // L1Flags words of the fused decode path
     DevBuf exttmp;              // intermediates of the two-pass forward level (extension modes that compute their samples)
@@ -109,6 +110,9 @@ struct spiht_ctx {
     int opt_wide_solo = 24576;  // list entries up to which a plane stays with workgroup 0 (4 k ... 64 k measured the same)
     int opt_wide_g = 0;         // workgroups per image of that encoder (0: by the size of the image)
     int opt_wide_encode = 1;    // few images per call: one image on several CUs (2: whatever the image's size -- tests)
+    int wide_per_cu = -1;       // workgroups of k_encode_wide a CU holds (occupancy query, once; 0: unknown -> one)
+    std::vector<WideCtl> wide_forced;  // opt_wide_encode == 3 (tests): control blocks that say "gave up" before the launch
+    int wide_last_groups = 0;   // groups of the last several-CUs-per-image launch (spiht_ctx_wide_stats)
     DevBuf filt;                // the filters of wavelet `filt_wavelet` on the device, for the two-pass levels (any length)
     int filt_wavelet = -1;
     // decoder output of the fused image path: kept all-zero between calls (k_unscatter), so no per-call zero-fill
@@ -376,7 +380,11 @@ extern "C" int spiht_ctx_create_priority(int device, int priority, spiht_ctx **o
     spiht_ctx *ctx = new spiht_ctx();
     ctx->device = device;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->num_cu = prop.multiProcessorCount;
+        ctx->tilectr.lds_per_cu = (int32_t)std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, (size_t)1 << 30);
+    }
+    ctx->tilectr.num_cu = ctx->num_cu;
     hipError_t e;
     if (priority > 0) {
         int least = 0, greatest = 0;
@@ -598,11 +606,13 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
     a.err = (uint32_t *)ctx->err.p;
     memcpy(a.log2_thresh, ctx->log2_thresh, sizeof(a.log2_thresh));
     // Few images per call: each on a group of G workgroups (encode_wide.hip) instead of one -- a single image's list coding
-    // is bound by the one CU it runs on.  Every workgroup of a group must be resident at once: B * G within the CUs.
+    // is bound by the one CU it runs on.  Every workgroup of a group must be resident at once: B * G within what the device
+    // holds of that kernel (asked of the runtime once per context).
     int G = (int)std::min<uint64_t>(64, std::max<uint64_t>(2, g.n >> 18));
     if (ctx->opt_wide_g > 0) G = ctx->opt_wide_g;
-    G = std::min(G, ctx->num_cu / std::max(B, 1));
-    if (ctx->opt_wide_encode && G >= 2 && (g.n >= (1u << 18) || ctx->opt_wide_encode == 2) && nslots >= B) {
+    if (ctx->wide_per_cu < 0) ctx->wide_per_cu = std::max(0, spiht_wide_groups_per_cu());
+    G = std::min(G, std::max(1, ctx->wide_per_cu) * ctx->num_cu / std::max(B, 1));
+    if (ctx->opt_wide_encode && G >= 2 && (g.n >= (1u << 18) || ctx->opt_wide_encode >= 2) && nslots >= B) {
         WideArgs w;
         const uint64_t cap_max = std::max<uint64_t>(caps.lip, std::max<uint64_t>(caps.lsp, caps.lis));
         w.maxchunks = (uint32_t)(cap_max / 2048 + 2);  // (the smaller of the two chunk sizes: WIDE_U * 1024 entries)
@@ -615,9 +625,20 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
         w.desc = (uint64_t *)((char *)ctx->widebuf.p + ctl_bytes);
         StageTimer t(ctx, ST_ENC_LISTS);
         HIPCHK(hipMemsetAsync(ctx->widebuf.p, 0, ctl_bytes + desc_bytes, ctx->stream));
-        // The workgroups of a group wait for one another, so a grid must become resident as a whole: two such grids of
-        // different contexts, each half resident on a full GPU, would wait for ever.  One at a time per device, by an
-        // event chain between the contexts' streams (the host does not block).
+        ctx->wide_last_groups = B;
+        if (ctx->opt_wide_encode == 3) {  // tests: every group finds itself given up -> k_encode<redo> codes every image
+            HIPCHK(hipStreamSynchronize(ctx->stream));  // (an earlier launch may still copy from the vector)
+            WideCtl gave_up;
+            memset(&gave_up, 0, sizeof(gave_up));
+            gave_up.bad = 2u;
+            ctx->wide_forced.assign((size_t)B, gave_up);
+            HIPCHK(hipMemcpyAsync(ctx->widebuf.p, ctx->wide_forced.data(), (size_t)B * sizeof(WideCtl), hipMemcpyHostToDevice, ctx->stream));
+        }
+        // The workgroups of a group wait for one another, so a grid should become resident as a whole: two such grids of
+        // different contexts, each half resident on a full GPU, would wait for each other.  One at a time per device, by an
+        // event chain between the contexts' streams (the host does not block).  What that chain cannot see -- another
+        // process, another kernel holding the CUs -- ends in the group giving up after a bounded wait (encode_wide.hip), and
+        // the launch of k_encode<redo> right behind codes exactly those images with one workgroup each: same bits, later.
         static std::mutex wide_mu;
         static hipEvent_t wide_last[64] = {};
         {
@@ -628,6 +649,9 @@ static int encode_lists_device(spiht_ctx *ctx, const Geom &g, const int32_t *d_x
             LAUNCHCHK(spiht_launch_encode_wide(&a, &w, B, ctx->stream));
             HIPCHK(hipEventRecord(ev, ctx->stream));
         }
+        a.redo = w.ctl;
+        a.nslots = B;
+        LAUNCHCHK(spiht_launch_encode(&a, ctx->stream));
         return SPIHT_OK;
     }
     {
@@ -1149,18 +1173,21 @@ static int dwt_forward(spiht_ctx *ctx, const double *d_img, int planes, int c, c
     // nobody else writes into it: a caller that owns its arrays says so (option "pads_persist": the pipeline's
     // double-buffered arrays; beside a list decoder this launch of thin strips took 0.74 instead of 0.12 ms per step).
     bool pads_known = false;
-    const spiht_ctx::PadKey key = {d_coeffs, planes, ig.hs[0], ig.ws[0], wv.F, ig.L};
+    // (the mode belongs to the key: periodization packs the bands by another length rule, i.e. other strips)
+    const spiht_ctx::PadKey key = {d_coeffs, planes, ig.hs[0], ig.ws[0], wv.F, ig.L, mode == SPIHT_MODE_PERIODIZATION ? 1 : 0};
     if (ctx->opt_pads_persist)
         for (const auto &k : ctx->pads_zeroed)
-            pads_known = pads_known || (k.p == key.p && k.planes == key.planes && k.H == key.H && k.W == key.W && k.F == key.F && k.L == key.L);
+            pads_known = pads_known || (k.p == key.p && k.planes == key.planes && k.H == key.H && k.W == key.W && k.F == key.F && k.L == key.L &&
+                                        k.mode == key.mode);
     if (!pads_known) {
         StageTimer t(ctx, ST_MEMSET);
         LAUNCHCHK(spiht_launch_zero_pads(ig.L, ig.hs, ig.ws, ig.offh, ig.offw, (int)ig.enc_h, (int)ig.enc_w, d_coeffs, planes,
                                          ctx->stream));
+        // (an array seen with another geometry before has other strips: forget it -- whether or not this call may rely
+        // on the promise, so that a later one that does never finds a record older than the array's last layout)
+        auto &v = ctx->pads_zeroed;
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const spiht_ctx::PadKey &k) { return k.p == key.p; }), v.end());
         if (ctx->opt_pads_persist) {
-            // (an array seen with another geometry before has other strips: forget it)
-            auto &v = ctx->pads_zeroed;
-            v.erase(std::remove_if(v.begin(), v.end(), [&](const spiht_ctx::PadKey &k) { return k.p == key.p; }), v.end());
             if (v.size() >= 8) v.erase(v.begin());
             v.push_back(key);
         }
@@ -1857,11 +1884,43 @@ extern "C" int spiht_ctx_set_option(spiht_ctx *ctx, const char *name, int64_t va
     const bool b01 = value == 0 || value == 1;
     if (!strcmp(name, "l1_flags") && b01) ctx->opt_l1_flags = value != 0;
     else if (!strcmp(name, "idwt_groups") && value <= 8) ctx->tilectr.wg_per_cu = (int32_t)value;
-    else if (!strcmp(name, "wide_encode") && value <= 2) ctx->opt_wide_encode = (int)value;
+    else if (!strcmp(name, "wide_encode") && value <= 3) ctx->opt_wide_encode = (int)value;
     else if (!strcmp(name, "wide_groups") && value <= 256) ctx->opt_wide_g = (int)value;
     else if (!strcmp(name, "wide_solo") && value <= (1 << 30)) ctx->opt_wide_solo = (int)value;
-    else if (!strcmp(name, "pads_persist") && b01) { ctx->opt_pads_persist = value != 0; ctx->pads_zeroed.clear(); }
+    else if (!strcmp(name, "pads_persist") && b01) ctx->opt_pads_persist = value != 0;
     else return SPIHT_ERR_ARG;
+    return SPIHT_OK;
+}
+extern "C" int spiht_ctx_get_option(spiht_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!strcmp(name, "l1_flags")) *value = ctx->opt_l1_flags;
+    else if (!strcmp(name, "idwt_groups")) *value = ctx->tilectr.wg_per_cu;
+    else if (!strcmp(name, "wide_encode")) *value = ctx->opt_wide_encode;
+    else if (!strcmp(name, "wide_groups")) *value = ctx->opt_wide_g;
+    else if (!strcmp(name, "wide_solo")) *value = ctx->opt_wide_solo;
+    else if (!strcmp(name, "pads_persist")) *value = ctx->opt_pads_persist;
+    else if (!strcmp(name, "num_cu")) *value = ctx->num_cu;                    // (read-only: what the device reports)
+    else if (!strcmp(name, "lds_per_cu")) *value = ctx->tilectr.lds_per_cu;
+    else return SPIHT_ERR_ARG;
+    return SPIHT_OK;
+}
+
+// The last encode call of this context that ran the several-CUs-per-image encoder: how many images (groups of workgroups)
+// it had and how many of those groups gave up for lack of residency and were coded by the single-workgroup kernel behind
+// it instead (csrc/encode_wide.hip).  Waits for the context's stream.  No such call yet: 0, 0.
+extern "C" int spiht_ctx_wide_stats(spiht_ctx *ctx, uint32_t *groups, uint32_t *gave_up) {
+    if (!ctx) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const int n = ctx->widebuf.p ? ctx->wide_last_groups : 0;
+    std::vector<WideCtl> h((size_t)n);
+    if (n) HIPCHK(hipMemcpy(h.data(), ctx->widebuf.p, (size_t)n * sizeof(WideCtl), hipMemcpyDeviceToHost));
+    uint32_t gu = 0;
+    for (const WideCtl &c : h) gu += (c.bad & 2u) ? 1u : 0u;
+    if (groups) *groups = (uint32_t)n;
+    if (gave_up) *gave_up = gu;
     return SPIHT_OK;
 }
 
@@ -1901,6 +1960,22 @@ extern "C" int spiht_ctx_set_color3(spiht_ctx *ctx, const double *A_f, const dou
     ctx->col_fwd.p = p_f;
     ctx->col_inv.p = p_i;
     ctx->color_on = true;
+    return SPIHT_OK;
+}
+
+// what spiht_ctx_set_color3 last set (on == 0: nothing is set and the arrays are left alone); any output pointer may be NULL
+extern "C" int spiht_ctx_get_color3(spiht_ctx *ctx, int *on, double *A_f, double *M_f, double *p_f, double *A_i, double *M_i,
+                                    double *p_i) {
+    if (!ctx || !on) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    *on = ctx->color_on ? 1 : 0;
+    if (!ctx->color_on) return SPIHT_OK;
+    if (A_f) memcpy(A_f, ctx->col_fwd.A, 72);
+    if (M_f) memcpy(M_f, ctx->col_fwd.M, 72);
+    if (A_i) memcpy(A_i, ctx->col_inv.A, 72);
+    if (M_i) memcpy(M_i, ctx->col_inv.M, 72);
+    if (p_f) *p_f = ctx->col_fwd.p;
+    if (p_i) *p_i = ctx->col_inv.p;
     return SPIHT_OK;
 }
 
@@ -2211,6 +2286,78 @@ extern "C" int spiht_comm_allreduce_max_f64(spiht_ctx *ctx, spiht_comm *c, doubl
 extern "C" int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *c) {
     double one = 1.0;
     return spiht_comm_allreduce_max_f64(ctx, c, &one);
+}
+
+// ------------------------------------------------------------------------------------------------
+// page-locked host memory for the arrays the drop-in calls RETURN (spiht_wrapper.py:192-216 returns a new ndarray): a
+// device -> host copy into such memory is one DMA at the link's speed; into fresh pageable memory it is staged copies
+// plus a page fault per 4 KB (measured on a 1080p RGB picture, 49.8 MB: 4.2 ms against 1 ms).  Pooled, because pinning
+// is what costs: a freed buffer waits for the next request of about its size.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct HostPool {
+    std::mutex mu;
+    struct Buf { void *p; size_t cap; };
+    std::vector<Buf> free_list;            // oldest first
+    std::vector<Buf> live;                 // handed out
+    size_t pooled = 0, out = 0;
+    static constexpr size_t kMaxPooled = (size_t)1 << 30, kMaxOut = (size_t)4 << 30;
+};
+HostPool g_host_pool;
+}  // namespace
+
+// bytes of page-locked host memory (usable from every device).  SPIHT_ERR_NOMEM when the allocation fails or more than
+// 4 GiB are handed out already: the caller then takes ordinary memory (the calls accept any host pointer).
+extern "C" int spiht_host_alloc(uint64_t bytes, void **h_ptr) {
+    if (!h_ptr || bytes == 0) return SPIHT_ERR_ARG;
+    *h_ptr = nullptr;
+    HostPool &hp = g_host_pool;
+    std::lock_guard<std::mutex> lk(hp.mu);
+    if (hp.out + bytes > HostPool::kMaxOut) return SPIHT_ERR_NOMEM;
+    int best = -1;
+    for (size_t i = 0; i < hp.free_list.size(); i++)
+        if (hp.free_list[i].cap >= bytes && hp.free_list[i].cap <= bytes + bytes / 4 + 4096 &&
+            (best < 0 || hp.free_list[i].cap < hp.free_list[(size_t)best].cap)) best = (int)i;
+    HostPool::Buf b;
+    if (best >= 0) {
+        b = hp.free_list[(size_t)best];
+        hp.free_list.erase(hp.free_list.begin() + best);
+        hp.pooled -= b.cap;
+    } else {
+        b.cap = (size_t)bytes;
+        if (hipHostMalloc(&b.p, b.cap, hipHostMallocPortable) != hipSuccess) {
+            (void)hipGetLastError();
+            // (room may be what is missing: the pool gives its buffers back and the request is tried once more)
+            for (auto &f : hp.free_list) (void)hipHostFree(f.p);
+            hp.free_list.clear();
+            hp.pooled = 0;
+            if (hipHostMalloc(&b.p, b.cap, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return SPIHT_ERR_NOMEM; }
+        }
+    }
+    hp.live.push_back(b);
+    hp.out += b.cap;
+    *h_ptr = b.p;
+    return SPIHT_OK;
+}
+extern "C" int spiht_host_free(void *h_ptr) {
+    if (!h_ptr) return SPIHT_OK;
+    HostPool &hp = g_host_pool;
+    std::lock_guard<std::mutex> lk(hp.mu);
+    for (size_t i = 0; i < hp.live.size(); i++) {
+        if (hp.live[i].p != h_ptr) continue;
+        const HostPool::Buf b = hp.live[i];
+        hp.live.erase(hp.live.begin() + (long)i);
+        hp.out -= b.cap;
+        hp.free_list.push_back(b);
+        hp.pooled += b.cap;
+        while (hp.pooled > HostPool::kMaxPooled || hp.free_list.size() > 8) {  // the oldest goes back to the system
+            (void)hipHostFree(hp.free_list.front().p);
+            hp.pooled -= hp.free_list.front().cap;
+            hp.free_list.erase(hp.free_list.begin());
+        }
+        return SPIHT_OK;
+    }
+    return SPIHT_ERR_ARG;  // not one of ours
 }
 
 // ------------------------------------------------------------------------------------------------

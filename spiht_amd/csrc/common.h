@@ -54,6 +54,26 @@ struct ListCaps {
     uint32_t pad;
 };
 
+// One image on several CUs (encode_wide.hip): per group of workgroups a control block and the descriptors of the chunk scan.
+struct WideCtl {          // zero-filled before every launch
+    uint32_t bar_count, bar_gen;  // the group's barrier: arrivals (monotonic), released epoch
+    uint32_t go;          // workgroup 0 has handed over: st[] is valid
+    uint32_t bad;         // 1: a list capacity exceeded; 2: a wait ran out of time -- the group's workgroups were not all
+                          // resident (other kernels held the CUs): everyone leaves, k_encode codes the image again
+    uint32_t st[12];      // n, lip_len, lsp_len, lis_len, bitpos lo / hi, LIP buffer, LIS buffer, done
+    uint32_t tot[8];      // totals of the pass just finished, two sets (pass number & 1)
+    uint32_t bad_at;      // ~(pass number) of the first pass in which a capacity was exceeded (atomicMax), 0: none
+    uint32_t pad[3];
+};
+struct WideArgs {
+    WideCtl *ctl;         // [groups]
+    uint64_t *desc;       // [groups][2][maxchunks][4] words [pass number | count]: aggregates, inclusive prefixes; zero-filled
+    uint32_t maxchunks;
+    uint32_t G;           // workgroups per image
+    uint32_t solo;        // entries on the three lists together up to which a plane is coded by workgroup 0 alone
+    uint32_t pad;
+};
+
 struct EncArgs {
     Geom g;
     ListCaps caps;
@@ -71,24 +91,8 @@ struct EncArgs {
     // scratch, per slot
     uint32_t *lip0, *lip1, *lsp, *lis0, *lis1, *lis2;
     uint32_t *err;           // device error word
+    const WideCtl *redo;     // k_encode behind k_encode_wide: codes only the images whose group gave up (bad & 2); else null
     float log2_thresh[32];   // log2_thresh[k]: smallest float m < 2^k with (u8)log2f(m) == k (host libm), or 2^k
-};
-
-// One image on several CUs (encode_wide.hip): per group of workgroups a control block and the descriptors of the chunk scan.
-struct WideCtl {          // zero-filled before every launch
-    uint32_t bar_count, bar_gen;  // the group's barrier: arrivals (monotonic), released epoch
-    uint32_t go;          // workgroup 0 has handed over: st[] is valid
-    uint32_t bad;         // 1: a list capacity exceeded, 2: a spin limit hit
-    uint32_t st[12];      // n, lip_len, lsp_len, lis_len, bitpos lo / hi, LIP buffer, LIS buffer, done
-    uint32_t tot[8];      // totals of the pass just finished, two sets (pass number & 1)
-};
-struct WideArgs {
-    WideCtl *ctl;         // [groups]
-    uint64_t *desc;       // [groups][2][maxchunks][4] words [pass number | count]: aggregates, inclusive prefixes; zero-filled
-    uint32_t maxchunks;
-    uint32_t G;           // workgroups per image
-    uint32_t solo;        // entries on the three lists together up to which a plane is coded by workgroup 0 alone
-    uint32_t pad;
 };
 
 // Tile of the inverse level-1 kernels (dwt.hip), in output positions; in band positions half of it.
@@ -199,6 +203,8 @@ struct TileCtr {
     uint32_t *dev;      // 8 counters, 32 words apart (a memory line each); zero when allocated
     uint32_t base[8];   // host-side: value of each counter before the next launch
     int32_t wg_per_cu;  // persistent workgroups per CU of the next launches (0: the kernel's default, IWP_WG)
+    int32_t num_cu;     // of the context's device
+    int32_t lds_per_cu; // bytes of LDS a CU has (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
 };
 struct TileBase { uint32_t v[8]; };
 

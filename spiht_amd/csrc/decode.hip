@@ -12,7 +12,10 @@
 //     bit; only a fired type-A entry (1 + 4..8 bits) shifts what follows.  Wavefront 0, the sequencer, hops from fired
 //     A to fired A with a hand-written scalar loop (find-first-set on `bits & type-mask`, token length by v_readlane)
 //     and publishes, per 64-bit window, the mask of fired entries through an LDS ring.  Wavefront 1, the helper, runs
-//     ahead of it and prepares each window's bits and per-position token lengths.  The other wavefronts are workers:
+//     ahead of it and prepares each window's bits and per-position token lengths -- and, for the windows that meet a
+//     stretch of the queue that is all type A (most of them: profiles/r04_lis_type_runs.txt), the whole walk of the
+//     window for each of its nine possible entry points, so that the sequencer looks the window up instead of hopping
+//     through it.  The other wavefronts are workers:
 //     they rebuild entry starts from the mask, lane = stream position, and produce next generation / retained list /
 //     LIP / LSP appends; the running list lengths pass from worker to worker through a small LDS chain.
 //   * refinement: bit t belongs to LSP entry t -- all wavefronts, no sequencing.
@@ -130,6 +133,13 @@ struct DecShared {
             // stream), so that a worker's window costs it no stream load.  A worker can lag DEC_RING windows behind the
             // sequencer, the helper run DEC_PREP ahead of it.
             uint64_t wbits[DEC_PREP + DEC_RING][2];
+            // helper -> sequencer: the walk of each window under the hypothesis "every list entry this window meets is a
+            // type-A entry with offspring" -- then which bits are entries depends on the bits alone: an entry is '0' or
+            // '1' + 4..8 offspring bits, whatever its index in the queue.  Per entry point o = 0..8 (the window's first
+            // o bits belong to the previous window's last entry): tabfm = start positions of the fired entries, tabce =
+            // entries that start in the window | (bits the last one hangs over into the next window) << 7.
+            uint64_t tabfm[DEC_PREP][9];
+            uint16_t tabce[DEC_PREP][9];
         };
     };
     uint64_t wpart[DEC_NW];     // per-wave partials of the block scans
@@ -799,6 +809,39 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
             sh.plav[slot][lane] = (uint8_t)((bb & 1u) ? 5 + ns : 0);  // non-zero <=> the stream bit is 1
             if (lane < 2) sh.wbits[(j + u) % (DEC_PREP + DEC_RING)][lane] = lane ? hi : lo;
         }
+        // The batch's windows walked under the all-type-A hypothesis (DecShared::tabfm): lane = (window, entry points o,
+        // o + 4, o + 8); a walk is a dozen steps at most (a fired entry takes five bits or more).  Same token lengths as
+        // plav above: 5 + the significant ones among the four offspring bits pairs that follow.
+        {
+            static_assert(DEC_PREP_B == 16, "lane = window of the batch | entry-point group << 4");
+            asm volatile("" ::: "memory");  // (this wavefront's LDS writes above are read back below: in order)
+            const uint32_t uw = lane & 15u;
+            const uint64_t *wb = sh.wbits[(j + uw) % (DEC_PREP + DEC_RING)];
+            const uint64_t lo = wb[0], hi = wb[1];
+            const uint32_t tslot = (j + uw) % DEC_PREP;
+            for (uint32_t o = lane >> 4; o < 9u; o += 4u) {
+                uint32_t p = o, cnt = 0;
+                uint64_t fmk = 0;
+                while (p < 64u) {
+                    const uint64_t rem = lo >> p;
+                    if (rem == 0) { cnt += 64u - p; p = 64u; break; }  // zeros to the end: one-bit entries
+                    const uint32_t q = p + (uint32_t)__builtin_ctzll(rem);
+                    cnt += q - p + 1u;
+                    fmk |= 1ull << q;
+                    const uint64_t bq = q ? ((lo >> q) | (hi << (64u - q))) : lo;
+                    uint32_t pl = (uint32_t)(bq >> 1) & 0xFFu, ns = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const uint32_t sg = pl & 1u;
+                        pl >>= 1 + sg;
+                        ns += sg;
+                    }
+                    p = q + 5u + ns;
+                }
+                sh.tabfm[tslot][o] = fmk;
+                sh.tabce[tslot][o] = (uint16_t)(cnt | ((p - 64u) << 7));
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
     }
@@ -1146,6 +1189,22 @@ void k_decode(DecArgs a) {
                             const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
                             uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
                             asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
+                            // Every entry this window can meet is a type-A entry with offspring (64 of them: an entry takes a
+                            // bit at least), the window is whole and starts at most eight bits in (a token is nine bits at
+                            // most: true of every window but a phase's first): the helper has walked it for that entry point
+                            // already (DecShared::tabfm) -- one look-up instead of a hop per fired entry.  Four windows of
+                            // five on a 4096 x 4096 picture, one of two at 1080p (profiles/r04_lis_type_runs.txt).
+                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u) {
+                                const uint32_t tl = lane < 9u ? lane : 0u;
+                                const uint64_t tfm = sh.tabfm[pslot][tl];
+                                const uint32_t tce = sh.tabce[pslot][tl];
+                                fm = readlane64(tfm, pos0);
+                                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)pos0);
+                                rel = ce & 0x7Fu;
+                                pos = 64u + (ce >> 7);
+                                i += rel;
+                                PF_CNT(5, 1);
+                            } else {
                             const uint64_t lo = __ballot(LAv != 0);  // the window's bits (see DecShared::plav)
                             uint64_t Lr = lo >> pos, c64;
                             uint32_t f, dd, len;
@@ -1197,6 +1256,7 @@ void k_decode(DecArgs a) {
                                 pos += z;
                             }
                             i += rel;
+                            }
                         }
 #ifdef DEC_PROF
                         pf[13] += __builtin_amdgcn_s_memtime() - th;

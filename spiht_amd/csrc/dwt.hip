@@ -1544,17 +1544,26 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
     }
     const uint32_t gx = (uint32_t)((a.out_w + IW_TW - 1) / IW_TW), gy = (uint32_t)((a.out_h + IW_TH - 1) / IW_TH);
     const uint32_t nt = gx * gy * (uint32_t)planes;
-    static const int num_cu = [] {
-        int dev = 0, n = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        return n;
-    }();
     // a level with several tiles per workgroup slot (20 000 tiles and more: at 1080p, level 1 of 10 images): persistent
     // workgroups that fetch a tile ahead
     constexpr uint32_t pf_min = 20000u;
+    const int num_cu = tc ? tc->num_cu : 0;
     if (tc && tc->dev && num_cu >= 2 && nt >= pf_min && (uint64_t)(a.out_h + IW_TH) * a.out_w * 8u < (1ull << 31)) {  // (>= 8 workgroups: one per tile range at least)
-        const uint32_t G = (uint32_t)(num_cu * (tc->wg_per_cu > 0 ? tc->wg_per_cu : IWP_WG));
+        const int g = tc->wg_per_cu > 0 ? tc->wg_per_cu : IWP_WG;
+        const uint32_t G = (uint32_t)(num_cu * g);
+        // A caller that asks for g < IWP_WG workgroups per CU wants the rest of the CU for somebody else -- the pipelined
+        // schedule's list decoder, whose workgroup finds no registers beside four of these.  The grid is exactly g per CU,
+        // but where the workgroups land is the dispatcher's business: a CU that took g + 1 while the decoder's were arriving
+        // keeps a decoder workgroup waiting for the whole level (13.9 instead of 9.3 ms).  So the workgroups
+        // are made too large for a (g + 1)-th: LDS they do not use (dynamic, behind the kernel's own), just over 1 / (g + 1)
+        // of the CU's.  The placement is then the same whoever arrives first -- no timer between the launches.
+        uint32_t pad = 0;
+        if (g < IWP_WG && tc->lds_per_cu > 0) {
+            constexpr int HFk = F / 2;
+            constexpr uint32_t own = 4u * (IW_TH / 2 + HFk - 1) * (IW_TW / 2 + HFk) * 8u + 64u;  // s_b + s_next, rounded up
+            const uint32_t want = (uint32_t)tc->lds_per_cu / (uint32_t)(g + 1) + 512u;
+            if (want > own && want <= 65536u) pad = want - own;
+        }
         TileBase cb;
         uint32_t *ctr = tc->dev;
         for (uint32_t x = 0; x < 8; x++) {
@@ -1562,10 +1571,10 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
             // XCD x draws one number per tile of its range and two more per workgroup (the look-ahead past the end)
             tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
         }
-        if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
+        if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb);
         else if (a.flags && (uint64_t)a.enc_h * a.enc_w * 4u < (1ull << 31))
-            hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false, true>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb);
-        else { a.flags = nullptr; hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), 0, st, a, gx, gy, ctr, cb); }
+            hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false, true>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb);
+        else { a.flags = nullptr; hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {  // the launch did not happen: counters and book-keeping start over together
             (void)hipMemsetAsync(tc->dev, 0, 8 * 32 * sizeof(uint32_t), st);

@@ -110,6 +110,14 @@ void k_encode(EncArgs a) {
     uint32_t *q2 = a.lis2 + (size_t)slot * a.caps.lis;
 
     for (int b = (int)blockIdx.x; b < a.B; b += (int)gridDim.x) {
+        // behind k_encode_wide (a.redo: one slot per image): only the images whose group of workgroups gave up for lack of
+        // residency are coded here, from scratch -- what that kernel left in the slot goes first
+        if (a.redo) {
+            if (!(a.redo[b].bad & 2u)) continue;
+            uint32_t *zw = reinterpret_cast<uint32_t *>(a.out + (size_t)b * a.slot_stride);
+            for (uint64_t t = tid; t < a.slot_stride / 4; t += BLOCK) zw[t] = 0;
+            __syncthreads();
+        }
         const int32_t *__restrict__ X = a.x + (size_t)b * g.n;
         const uint8_t *__restrict__ DM = a.dmsb + (size_t)b * g.n;
         const uint8_t *__restrict__ LM = a.lmsb + (size_t)b * g.n;

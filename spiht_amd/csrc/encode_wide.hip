@@ -16,8 +16,13 @@
 //     shared with the neighbouring chunks -- with atomicOr (the slot is zero-filled before the launch);
 //   * the planes in which the lists are still short are coded by workgroup 0 alone -- the same code, the scan over the
 //     chunks kept in registers, no barriers -- and the others wait for its hand-over (WideCtl::go).
-// Every workgroup of a group has to be resident at the same time: the launcher keeps groups x G within the CUs.  Every
-// spin is bounded (a protocol bug must not hang the GPU): it ends in error bit 0x800.
+// Every workgroup of a group has to be resident at the same time.  The launcher keeps groups x G within what the device
+// holds of this kernel (occupancy query) and chains such launches of one process -- but another process, or any kernel
+// that holds the CUs, is outside that: so every wait is bounded by TIME (WIDE_TICKS, some tens of milliseconds), and a
+// workgroup whose wait runs out marks the group "not co-resident" (WideCtl::bad & 2), on which every workgroup of the
+// group leaves at its next look.  The launcher queues k_encode<redo> right behind this kernel: it codes exactly the images
+// whose group gave up, one workgroup each, from scratch -- the call never fails for lack of residency (the reference's
+// encode never fails on valid input, src/lib.rs:24-32), it only takes the single-workgroup time.
 #include "common.h"
 #include "encode_common.h"
 
@@ -26,12 +31,17 @@
 #define WIDE_U 2      // LIS entries per thread and chunk (consecutive in the queue); 4: 82 registers spilled
 #endif
 #define WIDE_V 8      // LIP / LSP entries per thread and chunk; a multiple of 4
-#define WIDE_SPIN (1u << 25)  // some tens of seconds: other kernels may hold the CUs a workgroup of the group waits for
+#define WIDE_TICKS 100000000ull  // s_memtime ticks (shader clocks: about 40 ms) a workgroup waits for another one of its group
 
 __device__ __forceinline__ uint64_t wd_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wd_store(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t wu_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wu_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// a wait of the group: false once it has lasted WIDE_TICKS or another workgroup has given up
+__device__ __forceinline__ bool wide_wait_ok(const uint32_t *badp, uint64_t t0) {
+    return !(wu_load(badp) & 2u) && __builtin_amdgcn_s_memtime() - t0 < WIDE_TICKS;
+}
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -73,9 +83,9 @@ __device__ __forceinline__ uint64_t wide_exscan(uint64_t v, uint64_t &total, Wid
 }
 
 // wave 0 of the workgroup: exclusive prefix E of chunk c of pass `tag` over the chunks before it; publishes this chunk's
-// aggregate A and its inclusive prefix.  false: a spin limit was hit.
+// aggregate A and its inclusive prefix.  false: the wait for a predecessor ran out (wide_wait_ok).
 __device__ __forceinline__ bool wide_lookback(uint64_t *aggD, uint64_t *incD, uint32_t c, uint32_t tag, const uint32_t (&A)[4],
-                                              uint32_t (&E)[4], uint32_t lane) {
+                                              uint32_t (&E)[4], uint32_t lane, const uint32_t *badp) {
     const uint64_t T = (uint64_t)tag << 32;
     const uint32_t mine = lane == 0 ? A[0] : lane == 1 ? A[1] : lane == 2 ? A[2] : lane == 3 ? A[3] : 0u;
     E[0] = E[1] = E[2] = E[3] = 0;
@@ -91,7 +101,7 @@ __device__ __forceinline__ bool wide_lookback(uint64_t *aggD, uint64_t *incD, ui
         const bool valid = p >= 0;
         uint32_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
         bool ok = !valid, isinc = false;
-        uint32_t spins = 0;
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
         for (;;) {
             if (!ok) {
                 uint64_t w0 = wd_load(&incD[(size_t)p * 4]), w1 = wd_load(&incD[(size_t)p * 4 + 1]);
@@ -115,7 +125,7 @@ __device__ __forceinline__ bool wide_lookback(uint64_t *aggD, uint64_t *incD, ui
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > WIDE_SPIN) { good = false; break; }
+            if (!wide_wait_ok(badp, t0)) { good = false; break; }
         }
         if (!good) break;
         const uint64_t incm = __ballot(valid && isinc);
@@ -144,6 +154,7 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
     const int b = (int)grp;
     if (b >= a.B) return;
     WideCtl *ctl = w.ctl + grp;
+    if (wu_load(&ctl->bad) & 2u) return;  // the group gave up before this workgroup got a CU: k_encode<redo> codes the image
     uint64_t *aggD = w.desc + (size_t)grp * 2 * w.maxchunks * 4, *incD = aggD + (size_t)w.maxchunks * 4;
 
     uint32_t *const lipbuf[2] = {a.lip0 + (size_t)grp * a.caps.lip, a.lip1 + (size_t)grp * a.caps.lip};
@@ -183,10 +194,10 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
             if (arrived == epoch * G) {
                 wu_store(&ctl->bar_gen, epoch);
             } else {
-                uint32_t spins = 0;
+                const uint64_t t0 = __builtin_amdgcn_s_memtime();
                 while (wu_load(&ctl->bar_gen) < epoch) {
                     __builtin_amdgcn_s_sleep(2);
-                    if (++spins > WIDE_SPIN) { atomicOr(&ctl->bad, 2u); break; }
+                    if (!wide_wait_ok(&ctl->bad, t0)) { atomicOr(&ctl->bad, 2u); break; }
                 }
             }
             __threadfence();
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
         }
         if (tid < 64) {
             uint32_t Ew[4];
-            if (!wide_lookback(aggD, incD, c, tag, A, Ew, lane)) atomicOr(&ctl->bad, 2u);
+            if (!wide_lookback(aggD, incD, c, tag, A, Ew, lane, &ctl->bad)) atomicOr(&ctl->bad, 2u);
             if (lane == 0) { sh.E[0] = Ew[0]; sh.E[1] = Ew[1]; sh.E[2] = Ew[2]; sh.E[3] = Ew[3]; }
         }
         __syncthreads();
@@ -247,7 +258,11 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < 4; k++) sh.bc[k] = nchunks ? wu_load(&ctl->tot[(tag & 1u) * 4 + k]) : 0u;  // (two sets: the next pass may finish early)
-            sh.bc[4] = wu_load(&ctl->bad);
+            // A capacity guard of THIS pass or an earlier one: every workgroup of the group reads the same answer behind
+            // the barrier of pass `tag`.  (A workgroup that is already in pass tag + 1 may have tripped a guard there: that
+            // one counts at the next barrier -- a workgroup leaving one barrier early would leave the others waiting.)
+            const uint32_t at = wu_load(&ctl->bad_at);
+            sh.bc[4] = (wu_load(&ctl->bad) & 2u) | ((at != 0u && ~at <= tag) ? 1u : 0u);
         }
         __syncthreads();
 #pragma unroll
@@ -286,10 +301,10 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
     } else {
         // wait for workgroup 0's hand-over
         if (tid == 0) {
-            uint32_t spins = 0;
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
             while (wu_load(&ctl->go) == 0) {
                 __builtin_amdgcn_s_sleep(8);
-                if (++spins > WIDE_SPIN) { atomicOr(&ctl->bad, 2u); break; }
+                if (!wide_wait_ok(&ctl->bad, t0)) { atomicOr(&ctl->bad, 2u); break; }
             }
             __threadfence();
             for (int k = 0; k < 9; k++) sh.bc[k] = wu_load(&ctl->st[k]);
@@ -372,7 +387,7 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
                 const uint64_t bit0 = bitpos + (uint64_t)base + E[0];  // one bit per entry before, one more per significant one
                 if (bit0 < max_bits) {  // (else the budget was spent before this chunk: nothing of it is kept)
                     if (lsp_len + E[0] + A[0] > a.caps.lsp || (base - E[0]) + (cnt - A[0]) > a.caps.lip) {
-                        if (tid == 0) atomicOr(&ctl->bad, 1u);
+                        if (tid == 0) { atomicOr(&ctl->bad, 1u); atomicMax(&ctl->bad_at, ~tag); }
                         if (solo) bad = true;
                     } else {
                         uint32_t os = lsp_len + E[0] + pS, ol = (base - E[0]) + (before - pS);
@@ -504,7 +519,7 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
                         const uint32_t tQ = A[3] + 4 * A[2], tR = cnt - A[1] - A[2], tLIP = 4 * A[1] - A[0], tLSP = A[0], tB = cnt + 4 * A[1] + A[0];
                         const uint32_t bQ = E[3] + 4 * E[2], bR = ret_len + (base - E[1] - E[2]), bLIP = lip_len + 4 * E[1] - E[0], bLSP = lsp_len + E[0];
                         if (bQ + tQ > a.caps.lis || bR + tR > a.caps.lis || bLIP + tLIP > a.caps.lip || bLSP + tLSP > a.caps.lsp) {
-                            if (tid == 0) atomicOr(&ctl->bad, 1u);
+                            if (tid == 0) { atomicOr(&ctl->bad, 1u); atomicMax(&ctl->bad_at, ~tag); }
                             if (solo) bad = true;
                         } else {
                             uint32_t oq = bQ + pQA + 4 * pFB, orr = bR + (before - pFA - pFB), ol = bLIP + 4 * pFA - pS, os = bLSP + pS,
@@ -604,14 +619,22 @@ __global__ __launch_bounds__(WB_BLOCK) void k_encode_wide(EncArgs a, WideArgs w)
                 __threadfence();
                 wu_store(&ctl->go, 1u);
             }
-            a.out_nbits[b] = bitpos;
-            a.out_maxn[b] = (uint8_t)max_n;
             const uint32_t cb_ = wu_load(&ctl->bad);
-            if (bad || (cb_ & 1u)) atomicOr(a.err, maxabs >= (1u << 30) ? 2u : 1u);
-            if (cb_ & 2u) atomicOr(a.err, 0x800u);
-            if (a.max_bits > capb && bitpos >= capb) atomicOr(a.err, 4u);
+            if (!(cb_ & 2u)) {  // (a group that gave up reports nothing: k_encode<redo> codes the image and reports for it)
+                a.out_nbits[b] = bitpos;
+                a.out_maxn[b] = (uint8_t)max_n;
+                if (bad || (cb_ & 1u)) atomicOr(a.err, maxabs >= (1u << 30) ? 2u : 1u);
+                if (a.max_bits > capb && bitpos >= capb) atomicOr(a.err, 4u);
+            }
         }
     }
+}
+
+// workgroups of k_encode_wide a CU holds at once (the launcher keeps groups x G within that times the CUs); < 1: unknown
+extern "C" int spiht_wide_groups_per_cu(void) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_encode_wide, WB_BLOCK, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
 }
 
 extern "C" int spiht_launch_encode_wide(const EncArgs *a, const WideArgs *w, int groups, hipStream_t st) {

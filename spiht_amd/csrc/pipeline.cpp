@@ -49,7 +49,44 @@ struct spiht_pipeline {
     bool pending = false;      // a batch whose inverse transform has not been queued yet
     int pending_slot = 0;
     double *pending_out = nullptr;
+    // colour model of the coded pictures (spiht_pipeline_set_color3): the pipeline's own, put on the H context around its calls
+    bool color_on = false;
+    double cAf[9], cMf[9], cAi[9], cMi[9], cpf = 1.0, cpi = 1.0;
+    uint32_t gap_us = 100;
+    int poisoned = SPIHT_OK;   // a call failed half-way: the schedule's state is void, every later call returns this
     const double *mp() const { return mults.empty() ? nullptr : mults.data(); }
+};
+
+// The H context may be the caller's (spiht_pipeline_create_on): nothing of the pipeline's stays on it between calls.  While a
+// call of the pipeline queues work it holds the context's mutex and has its own settings on it -- colour model, zero padding
+// written once per array (the coefficient arrays are the pipeline's own and only its forward transform writes them), three
+// persistent inverse-transform workgroups per CU (a decoder workgroup that arrives behind them still fits: registers) -- and
+// what the caller had there before comes back when the call returns.
+struct HScope {
+    spiht_pipeline *p;
+    int64_t old_pads = 0, old_groups = 0;
+    int old_on = 0;
+    double oAf[9], oMf[9], oAi[9], oMi[9], opf = 1.0, opi = 1.0;
+    int st = SPIHT_OK;
+    explicit HScope(spiht_pipeline *pp) : p(pp) {
+        st = spiht_ctx_lock(p->Hc);
+        if (st != SPIHT_OK) { p = nullptr; return; }
+        (void)spiht_ctx_get_option(p->Hc, "pads_persist", &old_pads);
+        (void)spiht_ctx_get_option(p->Hc, "idwt_groups", &old_groups);
+        (void)spiht_ctx_get_color3(p->Hc, &old_on, oAf, oMf, &opf, oAi, oMi, &opi);
+        (void)spiht_ctx_set_option(p->Hc, "pads_persist", 1);
+        (void)spiht_ctx_set_option(p->Hc, "idwt_groups", 3);
+        if (p->color_on) st = spiht_ctx_set_color3(p->Hc, p->cAf, p->cMf, p->cpf, p->cAi, p->cMi, p->cpi);
+        else st = spiht_ctx_set_color3(p->Hc, nullptr, nullptr, 1.0, nullptr, nullptr, 1.0);
+    }
+    ~HScope() {
+        if (!p) return;
+        (void)spiht_ctx_set_option(p->Hc, "pads_persist", old_pads);
+        (void)spiht_ctx_set_option(p->Hc, "idwt_groups", old_groups);
+        if (old_on) (void)spiht_ctx_set_color3(p->Hc, oAf, oMf, opf, oAi, oMi, opi);
+        else (void)spiht_ctx_set_color3(p->Hc, nullptr, nullptr, 1.0, nullptr, nullptr, 1.0);
+        (void)spiht_ctx_unlock(p->Hc);
+    }
 };
 
 static void pipeline_free(spiht_pipeline *p) {
@@ -71,7 +108,6 @@ static void pipeline_free(spiht_pipeline *p) {
     for (int s = 0; s < 2; s++)
         if (p->Lc[s]) spiht_ctx_destroy(p->Lc[s]);
     if (p->Hc && p->owns_h) spiht_ctx_destroy(p->Hc);
-    else if (p->Hc) { (void)spiht_ctx_set_option(p->Hc, "pads_persist", 0); (void)spiht_ctx_set_option(p->Hc, "idwt_groups", 0); }
     delete p;
 }
 
@@ -93,8 +129,6 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
     if (st != SPIHT_OK) { pipeline_free(p); return st; }
     if (p->slot_stride < 4) p->slot_stride = 4;
     if (!p->Hc && (st = spiht_ctx_create(device, &p->Hc)) != SPIHT_OK) { pipeline_free(p); return st; }
-    // the coefficient arrays are the pipeline's own and only its forward transform writes them: zero padding written once
-    (void)spiht_ctx_set_option(p->Hc, "pads_persist", 1);
     const uint64_t n = (uint64_t)c * p->enc_h * p->enc_w;
     for (int s = 0; s < 2 && st == SPIHT_OK; s++) {
         if ((st = spiht_ctx_create(device, &p->Lc[s])) != SPIHT_OK) break;
@@ -124,9 +158,11 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
         if (st == SPIHT_OK && a_h > 0 && a_w > 0 && mode != SPIHT_MODE_PERIODIZATION)
             st = spiht_dev_alloc(p->Hc, (uint64_t)B * c * a_h * a_w * 8, (void **)&p->approx);
     }
-    // three persistent inverse-transform workgroups per CU instead of four: a decoder workgroup that arrives behind them
-    // still fits (registers), see queue_inverse_*
-    if (st == SPIHT_OK) (void)spiht_ctx_set_option(p->Hc, "idwt_groups", 3);
+    p->gap_us = 0;
+    if (const char *e = getenv("SPIHT_EXP_GAP_US")) {  // EXPERIMENT (round 4, to be removed): the timer the LDS pad replaces
+        const long v = atol(e);
+        p->gap_us = (uint32_t)(v < 0 ? 0 : v > 10000 ? 10000 : v);
+    }
     if (st == SPIHT_OK) st = spiht_ctx_synchronize(p->Hc);
     if (st != SPIHT_OK) { pipeline_free(p); return st; }
     *out = p;
@@ -166,7 +202,13 @@ extern "C" int spiht_pipeline_contexts(spiht_pipeline *p, spiht_ctx **h, spiht_c
 extern "C" int spiht_pipeline_set_color3(spiht_pipeline *p, const double *A_f, const double *M_f, double p_f, const double *A_i,
                                          const double *M_i, double p_i) {
     if (!p) return SPIHT_ERR_ARG;
-    return spiht_ctx_set_color3(p->Hc, A_f, M_f, p_f, A_i, M_i, p_i);  // (the contexts are the pipeline's own: set for good)
+    if (!A_f) { p->color_on = false; return SPIHT_OK; }
+    if (!M_f || !A_i || !M_i) return SPIHT_ERR_ARG;
+    memcpy(p->cAf, A_f, sizeof(p->cAf)); memcpy(p->cMf, M_f, sizeof(p->cMf));
+    memcpy(p->cAi, A_i, sizeof(p->cAi)); memcpy(p->cMi, M_i, sizeof(p->cMi));
+    p->cpf = p_f; p->cpi = p_i;
+    p->color_on = true;  // (kept by the pipeline, put on the H context around each of its calls: HScope)
+    return SPIHT_OK;
 }
 
 // The inverse transform of batch s in two parts.  Part 1: the coarse levels, queued beside the encoder of the batch after it;
@@ -200,11 +242,8 @@ static int queue_inverse(spiht_pipeline *p, int s, double *d_img_out) {
     return queue_inverse_level1(p, s, d_img_out);
 }
 
-extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits,
-                                            uint8_t *d_max_n, double *d_img_out, spiht_comm *comm, uint8_t *d_all_slots,
-                                            uint64_t *d_all_nbits, uint8_t *d_all_max_n, int rank) {
-    if (!p || !d_img || !d_out || !d_nbits || !d_max_n || !d_img_out) return SPIHT_ERR_ARG;
-    if (comm && (!d_all_slots || !d_all_nbits || !d_all_max_n || rank < 0)) return SPIHT_ERR_ARG;
+static int submit_impl(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits, uint8_t *d_max_n, double *d_img_out,
+                       spiht_comm *comm, uint8_t *d_all_slots, uint64_t *d_all_nbits, uint8_t *d_all_max_n, int rank) {
     const int s = (int)(p->step & 1), o = s ^ 1;
     spiht_ctx *L = p->Lc[s];
     // H: front half of the encoder
@@ -234,8 +273,7 @@ extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_i
         // and a little later still: level 1's persistent workgroups (three per CU, launched at that moment) should have
         // settled evenly before the decoder's arrive -- dispatched in the same microseconds, some CUs end up with four of
         // them and no room for a decoder workgroup until the whole level is through (decoder 13.9 instead of 10 ms)
-        static const uint32_t gap_us = getenv("SPIHT_PIPELINE_GAP_US") ? (uint32_t)atoi(getenv("SPIHT_PIPELINE_GAP_US")) : 100u;
-        CHK(spiht_ctx_pause_us(L, gap_us));
+        CHK(spiht_ctx_pause_us(L, p->gap_us));
     }
     CHK(spiht_decode_lists_flags_batch_i32(L, x_out, p->slot_stride, p->nbytes[s], x_maxn, p->B, p->c, p->H, p->W, p->wavelet,
                                            p->mode, p->level, p->rec[s], p->flags[s]));
@@ -253,6 +291,21 @@ extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_i
     return SPIHT_OK;
 }
 
+extern "C" int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits,
+                                            uint8_t *d_max_n, double *d_img_out, spiht_comm *comm, uint8_t *d_all_slots,
+                                            uint64_t *d_all_nbits, uint8_t *d_all_max_n, int rank) {
+    if (!p || !d_img || !d_out || !d_nbits || !d_max_n || !d_img_out) return SPIHT_ERR_ARG;
+    if (comm && (!d_all_slots || !d_all_nbits || !d_all_max_n || rank < 0)) return SPIHT_ERR_ARG;
+    if (p->poisoned != SPIHT_OK) return p->poisoned;
+    HScope sc(p);
+    int st = sc.st;
+    if (st == SPIHT_OK) st = submit_impl(p, d_img, d_out, d_nbits, d_max_n, d_img_out, comm, d_all_slots, d_all_nbits, d_all_max_n, rank);
+    // a failure between the first and the last queued call leaves events, buffer sets and the pending inverse transform half
+    // advanced: nothing later can be trusted, and every later call says so with the first error
+    if (st != SPIHT_OK) p->poisoned = st;
+    return st;
+}
+
 extern "C" int spiht_pipeline_submit(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits, uint8_t *d_max_n,
                                      double *d_img_out) {
     return spiht_pipeline_submit_gather(p, d_img, d_out, d_nbits, d_max_n, d_img_out, nullptr, nullptr, nullptr, nullptr, 0);
@@ -260,8 +313,12 @@ extern "C" int spiht_pipeline_submit(spiht_pipeline *p, const double *d_img, uin
 
 extern "C" int spiht_pipeline_flush(spiht_pipeline *p) {
     if (!p) return SPIHT_ERR_ARG;
+    if (p->poisoned != SPIHT_OK) return p->poisoned;
     if (p->pending) {
-        CHK(queue_inverse(p, p->pending_slot, p->pending_out));
+        HScope sc(p);
+        int st = sc.st;
+        if (st == SPIHT_OK) st = queue_inverse(p, p->pending_slot, p->pending_out);
+        if (st != SPIHT_OK) { p->poisoned = st; return st; }
         p->pending = false;
     }
     return SPIHT_OK;
@@ -269,8 +326,7 @@ extern "C" int spiht_pipeline_flush(spiht_pipeline *p) {
 
 extern "C" int spiht_pipeline_synchronize(spiht_pipeline *p) {
     if (!p) return SPIHT_ERR_ARG;
-    CHK(spiht_pipeline_flush(p));
-    int st = SPIHT_OK;
+    int st = spiht_pipeline_flush(p);  // (a poisoned pipeline: the contexts are still waited for, the error reported)
     spiht_ctx *cs[3] = {p->Lc[0], p->Lc[1], p->Hc};
     for (spiht_ctx *cx : cs) {  // (every context is waited for, the first error is reported)
         const int s1 = spiht_ctx_synchronize(cx);

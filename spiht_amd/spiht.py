@@ -97,7 +97,7 @@ def decode(data_u8, n, c, h, w, ll_h, ll_w):
         return np.zeros((c, h, w), dtype=np.int32)
     ctx = _lib.default_context()
     L = _lib.lib()
-    out = np.empty((c, h, w), dtype=np.int32)
+    out = _lib.result_array((c, h, w), np.int32)
     st = L.spiht_decode_i32(ctx.handle, C.c_void_p(buf.ctypes.data if buf.size else 0), buf.size, n, c, h, w, ll_h, ll_w,
                             C.c_void_p(out.ctypes.data))
     _lib.check(st)

@@ -194,7 +194,7 @@ def decode_image(encoding_result: EncodingResult, spiht_settings: SpihtSettings,
     if n > 255:
         raise OverflowError("out of range integral type conversion attempted")
     mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
-    out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
+    out = _lib.result_array((c, g["rec_h"], g["rec_w"]), np.float64)  # (page-locked: the copy back is one DMA)
     ctx = _lib.default_context()
     if spiht_settings.color_model is not None and c != 3:
         raise ValueError("colour conversion needs 3 channels")
@@ -260,7 +260,7 @@ def decode_from_rec_arr(rec_arr: np.ndarray, h: int, w: int, level, spiht_settin
     mults, mults_p = _mults_arg(spiht_settings.per_channel_quant_scales, c)
     ctx = _lib.default_context()
     L = _lib.lib()
-    out = np.empty((c, g["rec_h"], g["rec_w"]), dtype=np.float64)
+    out = _lib.result_array((c, g["rec_h"], g["rec_w"]), np.float64)
     if spiht_settings.color_model is not None and c != 3:
         raise ValueError("colour conversion needs 3 channels")
     with color_models.fused(ctx, spiht_settings.color_model):

@@ -285,6 +285,40 @@ def test_pyramid_behind_the_forward_transform(oracle, case):
         a.free()
 
 
+def test_pads_persist_tells_layouts_of_one_array_apart(oracle):
+    """Option "pads_persist": the zero padding of coeffs_to_array is written once per array and layout.  Periodization packs
+    the bands by another length rule than the other modes -- other strips in the same array at the same picture size, filter
+    and level count -- so the record of an array must hold the mode's layout too: alternating reflect and periodization into
+    ONE buffer, every result must equal the oracle's array (a stale record would leave band values of the other layout in
+    padding cells, and the list coder would code them)."""
+    from spiht_amd import _lib
+    ctx, L = _lib.Context(0), _lib.lib()
+    c, H, W, wavelet, level, q = 2, 75, 118, "bior2.2", 3, 50.0
+    img = np.ascontiguousarray(synth_image(77, c, H, W)[None], np.float64)
+    wid = L.spiht_wavelet_id(wavelet.encode())
+    ref, shape = {}, {}
+    for mode in ("reflect", "periodization"):
+        arr, g = oracle.wavedec2_array(img[0], wavelet, mode, level)
+        ref[mode], shape[mode] = oracle.quantize(arr, q, None), (c, g["enc_h"], g["enc_w"])
+    assert shape["reflect"] != shape["periodization"]
+    nmax = max(int(np.prod(v)) for v in shape.values())
+    d_in, d_out = ctx.alloc(img.nbytes), ctx.alloc(nmax * 4)
+    try:
+        ctx.set_option("pads_persist", 1)
+        ctx.upload(d_in, img)
+        ctx.memset(d_out, 0xFF, nmax * 4)
+        for it, mode in enumerate(["reflect", "periodization", "reflect", "reflect", "periodization", "periodization"]):
+            mid = L.spiht_mode_id(mode.encode())
+            _lib.check(L.spiht_dwt_quant_batch_f64(ctx.handle, C.c_void_p(d_in), 1, c, H, W, wid, mid, level, q, None, C.c_void_p(d_out)))
+            got = np.empty(shape[mode], np.int32)
+            ctx.download(got, d_out)
+            assert np.array_equal(got, ref[mode]), (it, mode, int((got != ref[mode]).sum()))
+    finally:
+        ctx.free(d_in)
+        ctx.free(d_out)
+        ctx.close()
+
+
 def test_maxabs_small_batch_after_large_batch(oracle):
     """max|coefficient| of an image is raised by one atomic per workgroup, left out when a cached look at the word shows
     it holds as much already (dwt.hip: block_raise_max, MAXLOOK 1).  That look must never see a value from BEFORE the

@@ -654,6 +654,57 @@ def test_c_pipeline_matches_fused(cfg):
 
 
 @pytest.mark.gpu
+def test_pipeline_leaves_nothing_on_a_borrowed_context(oracle):
+    """spiht_pipeline_create_on runs the HBM-bound passes on the CALLER's context.  Its colour model and options are put on
+    that context only while one of its calls queues work: after an IPT pipeline has run there, a plain 3-channel encode /
+    decode on the same context codes RGB (stream and picture equal the oracle's); options the caller had set are what they
+    were; and a colour block of the caller's between two steps (set and clear on the shared context) does not take the
+    colour model away from the pipeline's later steps."""
+    import spiht_amd
+    from spiht_amd import _lib, color_models
+    from spiht_amd.batch import BatchCodec, DeviceArray, Pipeline
+    c, H, W, B, mb, level, steps = 3, 96, 136, 3, 9000, 3, 4
+    ctx = _lib.Context(0)
+    s_ipt = spiht_amd.SpihtSettings(quantization_scale=1.0, color_model="IPT", per_channel_quant_scales=[50.0, 15.0, 15.0])
+    s_rgb = spiht_amd.SpihtSettings()
+    codec_ipt, codec_rgb = BatchCodec(c, H, W, s_ipt, level, mb, ctx=ctx), BatchCodec(c, H, W, s_rgb, level, mb, ctx=ctx)
+    g = codec_ipt.geom
+    ctx.set_option("idwt_groups", 2)
+    pl = Pipeline(codec_ipt, B)
+    imgs = [np.stack([synth_image(800 + 10 * st + b, c, H, W) for b in range(B)]) for st in range(steps)]
+    d_imgs = [DeviceArray(ctx, (B, c, H, W), np.float64) for _ in range(steps)]
+    d_recs = [DeviceArray(ctx, (B, c, g["rec_h"], g["rec_w"]), np.float64) for _ in range(steps)]
+    d_outs = [DeviceArray(ctx, (B, pl.slot_stride), np.uint8) for _ in range(steps)]
+    d_nbits, d_maxn = [DeviceArray(ctx, (B,), np.uint64) for _ in range(steps)], [DeviceArray(ctx, (B,), np.uint8) for _ in range(steps)]
+    for st in range(steps):
+        d_imgs[st].upload(imgs[st])
+    ctx.synchronize()
+    plain = []
+    for st in range(steps):
+        pl.submit(d_imgs[st].ptr, d_outs[st].ptr, d_nbits[st].ptr, d_maxn[st].ptr, d_recs[st].ptr)
+        assert (ctx.get_option("idwt_groups"), ctx.get_option("pads_persist")) == (2, 0)
+        # between the steps the caller codes RGB on the same context, and uses a colour block of its own
+        plain.append(codec_rgb.encode(imgs[st][:1])[0])
+        with color_models.fused(ctx, "IPT"):
+            pass
+    pl.synchronize()
+    for st in range(steps):
+        ref_bytes, ref_n, _g = oracle.encode_image(imgs[st][0], "bior2.2", "reflect", level, 50.0, None, mb)
+        assert plain[st].encoded_bytes == ref_bytes and plain[st].max_n == ref_n, st
+        res = codec_ipt.encode(imgs[st])  # the fused calls with the colour model: what the pipeline must have produced
+        nb, out, mn = d_nbits[st].download(), d_outs[st].download(), d_maxn[st].download()
+        for b in range(B):
+            assert int(mn[b]) == res[b].max_n and out[b, :(int(nb[b]) + 7) // 8].tobytes() == res[b].encoded_bytes, (st, b)
+        assert np.array_equal(d_recs[st].download(), np.stack(codec_ipt.decode(res))), st
+    dec = codec_rgb.decode([plain[0]])[0]
+    ref = oracle.decode_image(plain[0].encoded_bytes, plain[0].max_n, c, H, W, "bior2.2", level, 50.0, None)
+    assert np.array_equal(dec, ref)
+    pl.close()
+    assert (ctx.get_option("idwt_groups"), ctx.get_option("pads_persist")) == (2, 0)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_c_caller_of_the_pipeline(tmp_path):
     """INTEGRATION.md's C example for real: tests/native/pipeline_smoke.c, compiled with gcc against include/spiht_hip.h and
     linked with libspiht_hip.so, runs the pipelined round trip with no Python in the process; its per-step checksums of

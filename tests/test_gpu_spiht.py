@@ -453,6 +453,95 @@ def test_wide_encoder_matches_oracle(oracle):
         ctx.set_option("wide_encode", 1)
 
 
+def test_wide_encoder_falls_back_when_every_group_gives_up(oracle):
+    """A group of workgroups that finds itself "given up" (WideCtl::bad & 2: a wait ran out because the group was not all
+    resident) leaves at once, and the k_encode<redo> launch queued behind codes those images with one workgroup each, from
+    scratch: option "wide_encode" = 3 marks every group so before the launch.  Streams, bit counts and start planes equal the
+    oracle's; the statistics say every image went that way."""
+    import ctypes as C
+    from spiht_amd import _lib
+    from spiht_amd.batch import DeviceArray
+    ctx = _lib.Context(0)
+    try:
+        ctx.set_option("wide_encode", 3)
+        L, vp = _lib.lib(), C.c_void_p
+        for k, (c, h, w, lh, lw, scale, mb) in enumerate([(3, 300, 420, 5, 7, 3000.0, 123457), (1, 512, 512, 4, 4, 20000.0, UNLIMITED),
+                                                          (3, 131, 203, 3, 5, 800.0, 999)]):
+            x = synth_coeffs(500 + k, c, h, w, lh, lw, scale=scale)
+            d_ref, n_ref, nb_ref = oracle.encode_nbits(x, lh, lw, mb)
+            out = np.full(len(d_ref) + 64, 0xEE, np.uint8)
+            nbits, max_n = C.c_uint64(), C.c_uint8()
+            _lib.check(L.spiht_encode_i32(ctx.handle, vp(x.ctypes.data), c, h, w, h * w, w, 1, lh, lw, mb, vp(out.ctypes.data), out.size,
+                                          C.byref(nbits), C.byref(max_n)))
+            assert (int(nbits.value), int(max_n.value)) == (nb_ref, n_ref) and out[:len(d_ref)].tobytes() == d_ref, k
+            assert ctx.wide_stats() == (1, 1)
+        # a batch: some slots hold what the several-CUs kernel would have left (here: nothing), all come out right
+        xs = np.stack([synth_coeffs(520 + b, 3, 200, 280, 7, 9, scale=4000.0) for b in range(3)])
+        mb, slot = 150000, (150000 // 8 + 8) // 4 * 4
+        d_x, d_out = DeviceArray(ctx, xs.shape, np.int32), DeviceArray(ctx, (3, slot), np.uint8)
+        d_nbits, d_maxn = DeviceArray(ctx, (3,), np.uint64), DeviceArray(ctx, (3,), np.uint8)
+        d_x.upload(xs)
+        _lib.check(L.spiht_encode_batch_i32(ctx.handle, vp(d_x.ptr), 3, 3, 200, 280, 7, 9, mb, vp(d_out.ptr), slot, vp(d_nbits.ptr),
+                                            vp(d_maxn.ptr)))
+        ctx.synchronize()
+        assert ctx.wide_stats() == (3, 3)
+        out, nbits, maxn = d_out.download(), d_nbits.download(), d_maxn.download()
+        for b in range(3):
+            d_ref, n_ref, nb_ref = oracle.encode_nbits(xs[b], 7, 9, mb)
+            assert int(nbits[b]) == nb_ref and int(maxn[b]) == n_ref and out[b, :len(d_ref)].tobytes() == d_ref, b
+    finally:
+        ctx.close()
+
+
+def test_wide_encoder_beside_a_kernel_that_holds_the_cus(oracle, tmp_path):
+    """The reference's encode never fails on valid input (src/lib.rs:24-32).  The several-CUs-per-image encoder needs its
+    workgroups resident together, and a kernel of somebody else's can hold the CUs: tests/native/filler.hip (built here with
+    hipcc, launched on a stream the library knows nothing of) holds all CUs but 40 for 0.4 s -- one workgroup of 1024 threads
+    and 96 KB of LDS per CU, beside which a 1024-thread encoder workgroup finds no registers -- then a 1080p-sized array is
+    encoded with 64 workgroups asked for: 40 get a CU, 24 do not.  The group gives up after its bounded wait and the
+    single-workgroup kernel behind it codes the image: the stream is the oracle's and the call returns long before the
+    filler ends."""
+    import ctypes as C
+    import subprocess
+    import time
+    import spiht_amd
+    from spiht_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libfiller.so")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC",
+                           os.path.join(root, "tests", "native", "filler.hip"), "-o", so])
+    F = C.CDLL(so)
+    F.filler_launch.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_uint64]
+    c, h, w, lh, lw = 3, 1111, 1949, 13, 19
+    x = synth_coeffs(42, c, h, w, lh, lw)
+    mb = 1036800
+    d_ref, n_ref, _ = oracle.encode_nbits(x, lh, lw, mb)
+    ctx = _lib.default_context()
+    ctx.set_option("wide_groups", 64)
+    try:
+        d, n = spiht_amd.encode(x, lh, lw, mb)  # (sizes the context's buffers; alone: every group resident)
+        assert (d, n) == (d_ref, n_ref) and ctx.wide_stats() == (1, 0)
+        ncu = F.filler_num_cu()
+        assert ncu > 64
+        hold_s = 0.4
+        rc = F.filler_launch(ncu - 40, 1024, 96 * 1024, int(hold_s * 2.4e9))
+        if rc == -2:
+            pytest.skip("this device does not give a workgroup 96 KB of LDS: no way to hold a CU with one workgroup")
+        assert rc == 0
+        time.sleep(0.02)  # (the filler's workgroups are on the CUs)
+        t0 = time.perf_counter()
+        d, n = spiht_amd.encode(x, lh, lw, mb)
+        dt = time.perf_counter() - t0
+        groups, gave_up = ctx.wide_stats()
+        assert F.filler_wait() == 0
+        assert (d, n) == (d_ref, n_ref), "stream differs (groups %d, gave up %d, %.3f s)" % (groups, gave_up, dt)
+        assert dt < 0.6 * hold_s, "the encode call waited for the filler: %.3f s (gave up: %d)" % (dt, gave_up)
+        print("encode beside the filler: %.1f ms, groups that gave up: %d of %d" % (dt * 1e3, gave_up, groups))
+    finally:
+        F.filler_wait()
+        ctx.set_option("wide_groups", 0)
+
+
 def test_wide_encoder_from_two_contexts_at_once(oracle):
     """Two threads, a context each, 160 workgroups per image: the two grids together exceed the CUs, and the workgroups of
     a grid wait for one another -- half-resident twins would wait for ever.  The library chains such launches one at a
