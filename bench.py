@@ -139,9 +139,10 @@ def main():
                          "is distinct, seed 1000 + global image index)")
     ap.add_argument("--cpu-sample", type=int, default=24,
                     help="images the one-core CPU baseline codes (0 = skip both CPU legs); 24 = about 11 s of one core")
-    ap.add_argument("--cpu-cores", type=int, default=16,
-                    help="processes of the all-cores CPU leg, which codes EVERY distinct image of the batch once and is also "
-                         "the parity check of the timed GPU output (16 = the CPU share of a one-GPU box; <= 1: skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0,
+                    help="processes of the all-cores CPU leg (SURVEY.md 8d: one independent image per core), which codes EVERY "
+                         "distinct image of the batch once and is also the parity check of the timed GPU output.  0 (default): "
+                         "every CPU this process may run on (nproc: sched_getaffinity), at most one per image; 1: skip")
     ap.add_argument("--gen-workers", type=int, default=0, help="processes that synthesise the inputs (0 = cores / ranks, <= 16)")
     ap.add_argument("--pixels", choices=["float64", "float32"], default="float64",
                     help="pixel dtype.  float64 (default) is what the reference's loader produces and what the metric is quoted "
@@ -312,8 +313,12 @@ def main():
         for name, (ms, n) in cx.timing().items():
             o = stages.get(name, (0.0, 0))
             stages[name] = (o[0] + ms, o[1] + n)
+    dt_rank = [dt]
+    gather_ms_rank = [stages.get("gather", (0.0, 0))[0] / max(1, args.steps)]
     if group is not None:
-        dt = group.max(dt)
+        dt_rank = group.allgather(dt)
+        gather_ms_rank = group.allgather(gather_ms_rank[0])
+        dt = max(dt_rank)
 
     # ---- correctness of what was timed (outside the timed region) ----
     nbits = d_nbits.download()
@@ -526,9 +531,12 @@ def main():
                                     if cpipe is not None else "stages back to back"),
                        "max_bits": max_bits, "images_per_s": round(total_images / dt, 2),
                        "coeff_array": [C_IMG, g["enc_h"], g["enc_w"]], "ll": [g["ll_h"], g["ll_w"]],
+                       "per_rank_ms_per_step": [round(v / args.steps * 1e3, 3) for v in dt_rank],
                        "gather": (dict(comm.info(), library=_lib.lib().spiht_rccl_library().decode(),
-                                       where="spiht_gather_streams (ncclAllGather on the list-coding stream); "
-                                             "every rank decodes its rows of the gathered buffer")
+                                       stream_ms_per_step_per_rank=[round(v, 4) for v in gather_ms_rank],
+                                       bytes_per_rank_per_step=B * (slot + 9),
+                                       where="spiht_gather_streams (ncclAllGather on the list-coding stream, timed with an "
+                                             "event pair on that stream); every rank decodes its rows of the gathered buffer")
                                   if comm is not None else
                                   ({"failed": comm_error, "library": _lib.lib().spiht_rccl_library().decode(),
                                     "note": "RCCL did not come up: every rank coded and decoded its own "
@@ -571,10 +579,11 @@ def main():
             # distinct image of the batch once -- which is also the parity check of ALL of them
             checked = 0
             all_stream_ok = all_img_ok = True
-            if args.cpu_cores > 1 and pix == np.float64:
+            if args.cpu_cores != 1 and pix == np.float64:
                 import concurrent.futures as cf
                 import multiprocessing as mp
-                ncores = min(args.cpu_cores, os.cpu_count() or 1)
+                nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                ncores = max(2, min(args.cpu_cores if args.cpu_cores > 0 else nproc, nproc, nd, 512))
                 jobs = [(seeds[k::ncores], 1) for k in range(ncores) if seeds[k::ncores]]
                 with cf.ProcessPoolExecutor(max_workers=ncores, mp_context=mp.get_context("spawn")) as ex:
                     list(ex.map(_cpu_worker, [([seeds[0]], 1)] * ncores))  # start-up (imports, library load) outside the timing
@@ -584,7 +593,8 @@ def main():
                 npx = sum(r[0] for r in res)
                 result["cpu_baseline_all_cores"] = {
                     "value": round(npx / t_all / 1e6, 3), "unit": "Mpixels/s", "cores": ncores, "kind": "port",
-                    "sample": "%d processes, the batch's %d distinct 1080p images once each, %.2fs" % (ncores, nd, t_all)}
+                    "sample": "%d processes (nproc %d, host %d), the batch's %d distinct 1080p images once each, one image per "
+                              "process at a time, %.2fs" % (ncores, nproc, os.cpu_count() or 0, nd, t_all)}
                 for _, dd in res:
                     for seed, (sd, nby, mn, idg) in dd.items():
                         gd = gpu_dig[seed]

@@ -70,10 +70,16 @@ int spiht_event_create(spiht_ctx *ctx, spiht_event **out);
 void spiht_event_destroy(spiht_event *ev);
 int spiht_event_record(spiht_event *ev, spiht_ctx *ctx);
 int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *ev);
-/* Queues a kernel of one wavefront that does nothing for about `us` microseconds (<= 10 000): spacing between the kernels
- * of two contexts when the order in which their workgroups reach the CUs matters (csrc/pipeline.cpp: the inverse
- * transform's level 1 ahead of the list decoder queued beside it). */
-int spiht_ctx_pause_us(spiht_ctx *ctx, uint32_t us);
+/* Placement between two contexts' kernels without a timer (csrc/pipeline.cpp: the list decoder of a batch is launched
+ * behind the persistent workgroups of the previous batch's inverse level 1).  The large levels of the inverse transform run
+ * as persistent workgroups -- a fixed number per CU, each too large for one more than that number to fit -- that count
+ * themselves in as they start.  _resident_ticket: where that count lives and what it will read once every such launch
+ * queued on ctx SO FAR has all its workgroups on the CUs (*d_counter NULL: the context has no such counter).
+ * _wait_resident: queues on ctx's stream a one-wavefront kernel that waits for the count to reach target, at most
+ * timeout_us microseconds (<= 10 000; it never holds its stream for ever): what is queued behind it starts when those
+ * workgroups are resident. */
+int spiht_ctx_resident_ticket(spiht_ctx *ctx, const void **d_counter, uint32_t *target);
+int spiht_ctx_wait_resident(spiht_ctx *ctx, const void *d_counter, uint32_t target, uint32_t timeout_us);
 /* The context's HIP stream (*stream is a hipStream_t) so a caller can queue its own work -- e.g. the RCCL gather of
  * the streams between encode and decode -- in order with the library's. */
 int spiht_ctx_stream(spiht_ctx *ctx, void **stream);
@@ -397,6 +403,10 @@ typedef struct spiht_pipeline spiht_pipeline;
 int spiht_pipeline_submit_gather(spiht_pipeline *p, const double *d_img, uint8_t *d_out, uint64_t *d_nbits, uint8_t *d_max_n,
                                  double *d_img_out, spiht_comm *comm, uint8_t *d_all_slots, uint64_t *d_all_nbits,
                                  uint8_t *d_all_max_n, int rank);
+/* Where rank r's rows start in the gathered arrays, in bytes from each array's start (rank-major: rows [r*B, (r+1)*B)).
+ * Pure arithmetic, no device: callable anywhere. */
+int spiht_gather_row_offsets(int rank, int world, int64_t B, uint64_t slot_stride, uint64_t *off_slots, uint64_t *off_nbits,
+                             uint64_t *off_max_n);
 /* Host-side job control over the same communicator (both block): every rank has arrived and its context's queue is
  * empty; *value becomes the maximum over ranks. */
 int spiht_comm_barrier(spiht_ctx *ctx, spiht_comm *comm);

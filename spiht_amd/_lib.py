@@ -32,7 +32,7 @@ _lib_lock = threading.Lock()
 
 # every symbol include/spiht_hip.h declares
 SYMBOLS = [
-    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_create_priority", "spiht_ctx_pause_us",
+    "spiht_strerror", "spiht_last_hip_error", "spiht_abi_version", "spiht_ctx_create", "spiht_ctx_create_priority", "spiht_ctx_resident_ticket", "spiht_ctx_wait_resident",
     "spiht_ctx_destroy",
     "spiht_ctx_synchronize", "spiht_ctx_wait_on", "spiht_event_create", "spiht_event_destroy", "spiht_event_record",
     "spiht_ctx_wait_event", "spiht_ctx_stream", "spiht_dwt_pyramid_batch_f64", "spiht_encode_lists_batch_i32",
@@ -46,7 +46,7 @@ SYMBOLS = [
     "spiht_idwt_coarse_batch_f64", "spiht_idwt_level1_batch_f64", "spiht_idwt_level1_flags_batch_f64", "spiht_idwt_approx_shape",
     "spiht_encode_image_host_f64", "spiht_encode_image_host_f32", "spiht_decode_image_host_f64",
     "spiht_dequant_idwt_host_f64",
-    "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams",
+    "spiht_comm_unique_id", "spiht_comm_create", "spiht_comm_destroy", "spiht_comm_info", "spiht_gather_streams", "spiht_gather_row_offsets",
     "spiht_comm_barrier", "spiht_comm_allreduce_max_f64", "spiht_rccl_library", "spiht_ctx_lock", "spiht_ctx_unlock",
     "spiht_pipeline_create", "spiht_pipeline_create_on", "spiht_pipeline_destroy", "spiht_pipeline_info", "spiht_pipeline_set_color3", "spiht_pipeline_submit",
     "spiht_pipeline_submit_gather", "spiht_pipeline_flush", "spiht_pipeline_synchronize", "spiht_pipeline_contexts",
@@ -75,7 +75,8 @@ def lib():
         L.spiht_last_hip_error.restype = C.c_char_p
         L.spiht_ctx_create.argtypes = [i32, C.POINTER(vp)]
         L.spiht_ctx_create_priority.argtypes = [i32, i32, C.POINTER(vp)]
-        L.spiht_ctx_pause_us.argtypes = [vp, C.c_uint32]
+        L.spiht_ctx_resident_ticket.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_uint32)]
+        L.spiht_ctx_wait_resident.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
         L.spiht_ctx_destroy.argtypes = [vp]
         L.spiht_ctx_destroy.restype = None
         L.spiht_ctx_synchronize.argtypes = [vp]
@@ -143,6 +144,7 @@ def lib():
         L.spiht_comm_destroy.restype = None
         L.spiht_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
         L.spiht_gather_streams.argtypes = [vp, vp, vp, vp, vp, i64, u64, vp, vp, vp]
+        L.spiht_gather_row_offsets.argtypes = [i32, i32, i64, u64, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
         L.spiht_comm_barrier.argtypes = [vp, vp]
         L.spiht_comm_allreduce_max_f64.argtypes = [vp, vp, C.POINTER(C.c_double)]
         L.spiht_rccl_library.restype = C.c_char_p

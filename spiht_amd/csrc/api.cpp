@@ -72,10 +72,10 @@ static thread_local std::string g_hip_err;
 
 enum Stage {
     ST_H2D = 0, ST_D2H, ST_ABSMAX, ST_PYRAMID, ST_ENC_LISTS, ST_DEC_LISTS, ST_DWT_L1, ST_DWT_REST, ST_IDWT_REST,
-    ST_IDWT_L1, ST_MEMSET, ST_COUNT
+    ST_IDWT_L1, ST_MEMSET, ST_GATHER, ST_COUNT
 };
 static const char *STAGE_NAMES[ST_COUNT] = {"h2d", "d2h", "absmax", "pyramid", "encode_lists", "decode_lists",
-                                            "dwt_level1", "dwt_rest", "idwt_rest", "idwt_level1", "memset"};
+                                            "dwt_level1", "dwt_rest", "idwt_rest", "idwt_level1", "memset", "gather"};
 
 struct DevBuf {
     void *p = nullptr;
@@ -92,7 +92,7 @@ struct spiht_ctx {
     DevBuf x, dmsb, lmsb, maxabs, out, nbits, maxn, err, lists, coeffs, a0, a1, data, nbytes, rec, mults, img;
     DevBuf trace, meta;  // decode_with_metadata
     DevBuf tilebuf;      // tile counters of the persistent inverse-transform kernel
-    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0};
+    TileCtr tilectr = {nullptr, {0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0, 0};
     DevBuf himg, hrec;   // host-array image entry points: pixels in / out, coefficient array in
     std::vector<double> mults_host;  // what ctx->mults holds (uploaded again only when the scales change)
     // colour model of the coded picture (spiht_ctx_set_color3): applied inside level 1 of the transforms of 3-channel images
@@ -413,9 +413,9 @@ extern "C" int spiht_ctx_create_priority(int device, int priority, spiht_ctx **o
     int rc = ensure(ctx, ctx->err, 256);
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
     (void)hipMemset(ctx->err.p, 0, 256);
-    rc = ensure(ctx, ctx->tilebuf, 8 * 32 * sizeof(uint32_t));
+    rc = ensure(ctx, ctx->tilebuf, TILECTR_WORDS * sizeof(uint32_t));
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
-    (void)hipMemset(ctx->tilebuf.p, 0, 8 * 32 * sizeof(uint32_t));
+    (void)hipMemset(ctx->tilebuf.p, 0, TILECTR_WORDS * sizeof(uint32_t));
     ctx->tilectr.dev = (uint32_t *)ctx->tilebuf.p;
     *out = ctx;
     return SPIHT_OK;
@@ -2044,14 +2044,26 @@ extern "C" int spiht_ctx_wait_event(spiht_ctx *ctx, spiht_event *e) {
     return SPIHT_OK;
 }
 
-extern "C" int spiht_launch_pause(uint64_t ticks, hipStream_t st);
-// queues a kernel of one wavefront that does nothing for about `us` microseconds (at most 10 000)
-extern "C" int spiht_ctx_pause_us(spiht_ctx *ctx, uint32_t us) {
-    if (!ctx || us > 10000u) return SPIHT_ERR_ARG;
-    if (us == 0) return SPIHT_OK;
+extern "C" int spiht_launch_gate(const uint32_t *counter, uint32_t target, uint64_t ticks, hipStream_t st);
+// Placement between two contexts' kernels without a timer.  The large levels of the inverse transform run as persistent
+// workgroups (a fixed number per CU) that count themselves in as they start; a ticket says what that count will read once
+// every such launch queued on `ctx` SO FAR has all its workgroups on the CUs ...
+extern "C" int spiht_ctx_resident_ticket(spiht_ctx *ctx, const void **d_counter, uint32_t *target) {
+    if (!ctx || !d_counter || !target) return SPIHT_ERR_ARG;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    *d_counter = ctx->tilectr.dev ? (const void *)(ctx->tilectr.dev + TILECTR_STARTED) : nullptr;
+    *target = ctx->tilectr.started;
+    return SPIHT_OK;
+}
+// ... and this queues, on another context's stream, a one-wavefront kernel that waits for that count (at most timeout_us
+// microseconds, <= 10 000: it must not hold its stream for ever if the launch it waits for never comes): the work queued
+// behind it starts when those workgroups are resident.  d_counter NULL: nothing to wait for.
+extern "C" int spiht_ctx_wait_resident(spiht_ctx *ctx, const void *d_counter, uint32_t target, uint32_t timeout_us) {
+    if (!ctx || timeout_us > 10000u) return SPIHT_ERR_ARG;
+    if (!d_counter) return SPIHT_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
-    LAUNCHCHK(spiht_launch_pause((uint64_t)us * 2400u, ctx->stream));  // (s_memtime counts shader clocks, 2.1-2.4 GHz)
+    LAUNCHCHK(spiht_launch_gate((const uint32_t *)d_counter, target, (uint64_t)timeout_us * 2400u, ctx->stream));  // (s_memtime: shader clocks)
     return SPIHT_OK;
 }
 
@@ -2259,6 +2271,7 @@ extern "C" int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *c, const uint8_t
     if (B == 0) return SPIHT_OK;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->device));
+    StageTimer t(ctx, ST_GATHER);  // (the exchange's own time on the stream: a first multi-GPU run explains itself)
     NCCLCHK(g_rccl.GroupStart());
     ncclResult_t r1 = g_rccl.AllGather(d_slots, d_all_slots, (size_t)B * slot_stride, ncclUint8, c->comm, ctx->stream);
     ncclResult_t r2 = g_rccl.AllGather(d_nbits, d_all_nbits, (size_t)B, ncclUint64, c->comm, ctx->stream);
@@ -2267,6 +2280,18 @@ extern "C" int spiht_gather_streams(spiht_ctx *ctx, spiht_comm *c, const uint8_t
     NCCLCHK(r1);
     NCCLCHK(r2);
     NCCLCHK(r3);
+    return SPIHT_OK;
+}
+
+// Where rank r's rows start in the gathered arrays (rank-major: rows [r*B, (r+1)*B)), in bytes from each array's start --
+// what a rank's decoder reads after spiht_gather_streams.  Pure arithmetic (no device); spiht_pipeline_submit_gather uses it.
+extern "C" int spiht_gather_row_offsets(int rank, int world, int64_t B, uint64_t slot_stride, uint64_t *off_slots, uint64_t *off_nbits,
+                                        uint64_t *off_max_n) {
+    if (world < 1 || rank < 0 || rank >= world || B < 0 || !off_slots || !off_nbits || !off_max_n) return SPIHT_ERR_ARG;
+    if (slot_stride && (uint64_t)world * (uint64_t)B > UINT64_MAX / slot_stride) return SPIHT_ERR_TOO_LARGE;
+    *off_slots = (uint64_t)rank * (uint64_t)B * slot_stride;
+    *off_nbits = (uint64_t)rank * (uint64_t)B * sizeof(uint64_t);
+    *off_max_n = (uint64_t)rank * (uint64_t)B;
     return SPIHT_OK;
 }
 

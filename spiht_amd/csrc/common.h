@@ -200,12 +200,16 @@ struct DwtKArgs {
 // never reset -- the launcher knows how many numbers a launch draws from each (tiles + 2 per workgroup) and hands the
 // kernel the counter values it starts from (all arithmetic modulo 2^32).
 struct TileCtr {
-    uint32_t *dev;      // 8 counters, 32 words apart (a memory line each); zero when allocated
+    uint32_t *dev;      // 8 counters, 32 words apart (a memory line each), and a ninth (word 8 * 32): persistent workgroups
+                        // that have started, ever; zero when allocated
     uint32_t base[8];   // host-side: value of each counter before the next launch
     int32_t wg_per_cu;  // persistent workgroups per CU of the next launches (0: the kernel's default, IWP_WG)
     int32_t num_cu;     // of the context's device
     int32_t lds_per_cu; // bytes of LDS a CU has (hipDeviceProp_t::maxSharedMemoryPerMultiProcessor)
+    uint32_t started;   // host-side: what the ninth counter reads once every launch queued so far has all its workgroups on the CUs
 };
+#define TILECTR_WORDS (9 * 32)
+#define TILECTR_STARTED (8 * 32)
 struct TileBase { uint32_t v[8]; };
 
 struct IdwtKArgs {

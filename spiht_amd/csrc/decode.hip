@@ -146,6 +146,7 @@ struct DecShared {
     uint32_t wfun[DEC_NW];      // per-wave carry functions
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     uint32_t pprog;             // windows of this phase the helper has prepared
+    uint32_t tprog;             // ... and walked under the all-type-A hypothesis (DecShared::tabfm): a multiple of 32
     uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_RING/2 windows)
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
@@ -344,7 +345,7 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
 __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_t &fc, uint64_t fm, uint32_t e_start,
-                                            uint32_t pos0, uint32_t pos1, uint32_t lane, uint32_t kw) {
+                                            uint32_t pos0, uint32_t pos1, uint32_t lane, uint32_t kw, uint64_t *pfw = nullptr) {
     constexpr uint32_t HALF = DEC_RING / 2;
     // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of HALF
     if (fc == 0) {
@@ -358,10 +359,16 @@ __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_
             const uint32_t w = lane < DEC_NWK ? lane : 0u;
             const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
             uint32_t spins = 0;
+#ifdef DEC_PROF
+            const uint64_t tws = __builtin_amdgcn_s_memtime();
+#endif
             while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
             }
+#ifdef DEC_PROF
+            if (pfw) *pfw += __builtin_amdgcn_s_memtime() - tws;
+#endif
         }
     }
     asm volatile("s_add_i32 %0, %0, -1" : "+s"(fc) : : "scc");  // (asm: keeps the counter in an SGPR)
@@ -461,21 +468,27 @@ __device__ __forceinline__ int32_t replay_dup(const uint32_t (&ts)[3], const int
     int nx[3] = {-1, -1, -1};
     uint32_t mag[3] = {0, 0, 0};
     int top = 0;
-    for (int q = 0; q < cnt; q++) {
-        mag[q] = (uint32_t)(vs[q] < 0 ? -vs[q] : vs[q]);
-        nx[q] = 31 - (int)__clz((int)mag[q]);
-        top = nx[q] > top ? nx[q] : top;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        if (q < cnt) {
+            mag[q] = (uint32_t)(vs[q] < 0 ? -vs[q] : vs[q]);
+            nx[q] = 31 - (int)__clz((int)mag[q]);
+            top = nx[q] > top ? nx[q] : top;
+        }
     }
     int32_t cur = 0;
     for (int m = top; m >= 0; --m) {
-        for (int q = 0; q < cnt; q++)
-            if (nx[q] == m) {
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+            if (q < cnt && nx[q] == m) {
                 const int32_t base = m == 0 ? 1 : (int32_t)(3u << (m - 1));
                 cur = vs[q] < 0 ? -base : base;
             }
-        if ((uint32_t)m >= ref_plane)
-            for (int q = 0; q < cnt; q++)
-                if (nx[q] > m && ((uint32_t)m > ref_plane || ts[q] < ref_count)) cur = set_bit_i32(cur, (uint32_t)m, (mag[q] >> m) & 1u);
+        if ((uint32_t)m >= ref_plane) {
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+                if (q < cnt && nx[q] > m && ((uint32_t)m > ref_plane || ts[q] < ref_count)) cur = set_bit_i32(cur, (uint32_t)m, (mag[q] >> m) & 1u);
+        }
     }
     return cur;
 }
@@ -532,12 +545,13 @@ __device__ __forceinline__ void resolve_dups(const Geom &g, int32_t *out, const 
         uint32_t m2 = ld_l2(&mailA[t]), m3 = ld_l2(&mailB[t]);
         if (m2 > lsp_len) m2 = 0;  // (as above: only a dirty array can leave such a word)
         if (m3 > lsp_len) m3 = 0;
-        uint32_t ts[3] = {0, 0, 0};
-        int32_t vs[3] = {0, 0, 0};
-        int cnt = 0;
-        if (m3) { ts[cnt] = m3 - 1u; vs[cnt] = lsp_val[m3 - 1u]; cnt++; }
-        if (m2) { ts[cnt] = m2 - 1u; vs[cnt] = lsp_val[m2 - 1u]; cnt++; }
-        ts[cnt] = t; vs[cnt] = lsp_val[t]; cnt++;
+        // (no run-time index into the small arrays: the compiler would move them to LDS -- 24 bytes per thread of the block)
+        const uint32_t t3 = m3 ? m3 - 1u : 0u, t2 = m2 ? m2 - 1u : 0u;
+        const int32_t v3 = m3 ? lsp_val[t3] : 0, v2 = m2 ? lsp_val[t2] : 0, v1 = lsp_val[t];
+        const int cnt = 1 + (m2 ? 1 : 0) + (m3 ? 1 : 0);
+        // ascending LSP index: [m3,] [m2,] t
+        const uint32_t ts[3] = {m3 ? t3 : (m2 ? t2 : t), m3 ? (m2 ? t2 : t) : (m2 ? t : 0u), (m3 && m2) ? t : 0u};
+        const int32_t vs[3] = {m3 ? v3 : (m2 ? v2 : v1), m3 ? (m2 ? v2 : v1) : (m2 ? v1 : 0), (m3 && m2) ? v1 : 0};
         mailA[t] = (uint32_t)replay_dup(ts, vs, cnt, ref_plane, ref_count);
         mailB[t] = OWNER;
     });
@@ -809,41 +823,79 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
             sh.plav[slot][lane] = (uint8_t)((bb & 1u) ? 5 + ns : 0);  // non-zero <=> the stream bit is 1
             if (lane < 2) sh.wbits[(j + u) % (DEC_PREP + DEC_RING)][lane] = lane ? hi : lo;
         }
-        // The batch's windows walked under the all-type-A hypothesis (DecShared::tabfm): lane = (window, entry points o,
-        // o + 4, o + 8); a walk is a dozen steps at most (a fired entry takes five bits or more).  Same token lengths as
-        // plav above: 5 + the significant ones among the four offspring bits pairs that follow.
-        {
-            static_assert(DEC_PREP_B == 16, "lane = window of the batch | entry-point group << 4");
-            asm volatile("" ::: "memory");  // (this wavefront's LDS writes above are read back below: in order)
-            const uint32_t uw = lane & 15u;
-            const uint64_t *wb = sh.wbits[(j + uw) % (DEC_PREP + DEC_RING)];
-            const uint64_t lo = wb[0], hi = wb[1];
-            const uint32_t tslot = (j + uw) % DEC_PREP;
-            for (uint32_t o = lane >> 4; o < 9u; o += 4u) {
-                uint32_t p = o, cnt = 0;
-                uint64_t fmk = 0;
-                while (p < 64u) {
-                    const uint64_t rem = lo >> p;
-                    if (rem == 0) { cnt += 64u - p; p = 64u; break; }  // zeros to the end: one-bit entries
-                    const uint32_t q = p + (uint32_t)__builtin_ctzll(rem);
-                    cnt += q - p + 1u;
-                    fmk |= 1ull << q;
-                    const uint64_t bq = q ? ((lo >> q) | (hi << (64u - q))) : lo;
-                    uint32_t pl = (uint32_t)(bq >> 1) & 0xFFu, ns = 0;
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const uint32_t sg = pl & 1u;
-                        pl >>= 1 + sg;
-                        ns += sg;
-                    }
-                    p = q + 5u + ns;
-                }
-                sh.tabfm[tslot][o] = fmk;
-                sh.tabce[tslot][o] = (uint16_t)(cnt | ((p - 64u) << 7));
-            }
-        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
+        // Every second batch: the last 32 windows walked under the all-type-A hypothesis (DecShared::tabfm).  Lane = (window,
+        // half): each walks the window from entry point 0 in full -- a dozen steps at most, a fired entry takes five bits or
+        // more -- and then four of the other eight entry points (half 0: 1..4, half 1: 5..8) only until they fall in step
+        // with that walk, which they do after a token or two (the code synchronises itself).  Same token lengths as plav
+        // above: 5 + the significant ones among the four offspring that follow.  Behind the announcement of the batch: the
+        // sequencer never waits for a table, it hops through a window whose table is not there yet.
+#ifndef DEC_NO_TABLE  // EXPERIMENT (round 4): A/B without the tables
+        if ((j & DEC_PREP_B) != 0)
+#else
+        if (false)
+#endif
+        {
+            static_assert(DEC_PREP_B == 16 && DEC_PREP % 32 == 0, "two batches = the 32 windows of a table pass");
+            const uint32_t tb = j - DEC_PREP_B, uw = lane & 31u, hf = lane >> 5;
+            const uint64_t *wb = sh.wbits[(tb + uw) % (DEC_PREP + DEC_RING)];
+            asm volatile("" ::: "memory");  // (this wavefront's LDS writes above are read back here: in order)
+            const uint64_t lo = wb[0], hi = wb[1];
+            const uint32_t tslot = (tb + uw) % DEC_PREP;
+            auto tok_len = [&](uint32_t q) -> uint32_t {  // length of the fired entry that starts at bit q
+                const uint64_t bq = q ? ((lo >> q) | (hi << (64u - q))) : lo;
+                uint32_t pl = (uint32_t)(bq >> 1) & 0xFFu, ns = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t sg = pl & 1u;
+                    pl >>= 1 + sg;
+                    ns += sg;
+                }
+                return 5u + ns;
+            };
+            // entry point 0: S0 = every bit at which an entry starts, fm0 = the fired ones among them
+            uint64_t S0 = 0, fm0 = 0;
+            uint32_t p = 0;
+            while (p < 64u) {
+                const uint64_t rem = lo >> p;
+                if (rem == 0) { S0 |= ~0ull << p; p = 64u; break; }  // zeros to the end: one-bit entries
+                const uint32_t q = p + (uint32_t)__builtin_ctzll(rem);
+                S0 |= ((2ull << (q - p)) - 1ull) << p;  // the zeros p .. q-1 and the fired entry at q
+                fm0 |= 1ull << q;
+                p = q + tok_len(q);
+            }
+            const uint32_t exit0 = p - 64u;
+            if (hf == 0) {
+                sh.tabfm[tslot][0] = fm0;
+                sh.tabce[tslot][0] = (uint16_t)((uint32_t)__popcll(S0) | (exit0 << 7));
+            }
+            for (uint32_t o = 1u + 4u * hf; o < 5u + 4u * hf; o++) {
+                uint32_t pp = o, cnt = 0, ex = 0;
+                uint64_t fmk = 0;
+                for (;;) {
+                    if (pp >= 64u) { ex = pp - 64u; break; }  // never met the walk from 0
+                    // one-bit entries up to the next bit that is set or lies on the walk from 0
+                    const uint32_t z = (uint32_t)__builtin_ctzll(((lo | S0) >> pp) | (1ull << (63u - pp)));
+                    cnt += z;
+                    pp += z;
+                    if ((S0 >> pp) & 1ull) {  // in step from here on
+                        cnt += (uint32_t)__popcll(S0 >> pp);
+                        fmk |= fm0 & (~0ull << pp);
+                        ex = exit0;
+                        break;
+                    }
+                    if (!((lo >> pp) & 1ull)) { cnt += 1; ex = 0; pp = 64u; break; }  // (bit 63, a zero off the walk: the last entry)
+                    fmk |= 1ull << pp;
+                    cnt += 1;
+                    pp += tok_len(pp);
+                }
+                sh.tabfm[tslot][o] = fmk;
+                sh.tabce[tslot][o] = (uint16_t)(cnt | (ex << 7));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) lds_store(&sh.tprog, j + DEC_PREP_B);
+        }
     }
 }
 
@@ -912,14 +964,14 @@ void k_decode(DecArgs a) {
         uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
 #ifdef DEC_PROF
-        uint64_t pf[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t pf[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
 #endif
 
         __syncthreads();  // previous image fully finished with the shared state
         if (threadIdx.x == 0) {
             sh.head = 0; sh.phase_end[0] = SEQ_OPEN; sh.phase_end[1] = SEQ_OPEN; sh.bad = 0; sh.ndup = 0;
-            sh.pprog = 0; sh.sprog = 0;
+            sh.pprog = 0; sh.sprog = 0; sh.tprog = 0;
             for (int w = 0; w < DEC_NWK; w++) sh.wdone[w] = 0;
             for (int r = 0; r < DEC_RING; r++) { sh.chain[r].seq = 0; sh.ring[r].ready = 0; }
         }
@@ -958,6 +1010,9 @@ void k_decode(DecArgs a) {
         // its SIMD it must not queue for issue slots behind them
 #ifndef DEC_SEQ_NOPRIO
         if (wave == 0) __builtin_amdgcn_s_setprio(3);
+#ifdef DEC_HELPER_PRIO  // EXPERIMENT (round 4)
+        if (wave == 1) __builtin_amdgcn_s_setprio(DEC_HELPER_PRIO);
+#endif
 #endif
         bool done = bad;
         for (; !done; --n) {
@@ -1101,6 +1156,8 @@ void k_decode(DecArgs a) {
                     uint32_t sP = RFL(P), sSeq = RFL(seq);
                     const uint32_t widx0s = sP >> 6;  // first window of the phase (the helper starts there too)
                     uint32_t pknown = 0;              // windows known to be prepared
+                    uint32_t tknown = 0;              // ... and to have their all-type-A table (DecShared::tabfm)
+                    bool prev_table = false;          // the window before was looked up in that table
                     uint32_t sFc = (0u - sSeq) & (DEC_RING / 2 - 1);  // publishes until the next ring-space check
                     const uint32_t cur_len_v = cur_len;
                     const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
@@ -1172,6 +1229,7 @@ void k_decode(DecArgs a) {
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
+                        bool by_table = false;
 #ifdef DEC_PROF
                         const uint64_t th = __builtin_amdgcn_s_memtime();
                         pf[12] += th - tw;
@@ -1194,7 +1252,8 @@ void k_decode(DecArgs a) {
                             // most: true of every window but a phase's first): the helper has walked it for that entry point
                             // already (DecShared::tabfm) -- one look-up instead of a hop per fired entry.  Four windows of
                             // five on a 4096 x 4096 picture, one of two at 1080p (profiles/r04_lis_type_runs.txt).
-                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u) {
+                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw >= tknown) tknown = RFL(lds_load(&sh.tprog));
+                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw < tknown) {
                                 const uint32_t tl = lane < 9u ? lane : 0u;
                                 const uint64_t tfm = sh.tabfm[pslot][tl];
                                 const uint32_t tce = sh.tabce[pslot][tl];
@@ -1203,6 +1262,7 @@ void k_decode(DecArgs a) {
                                 rel = ce & 0x7Fu;
                                 pos = 64u + (ce >> 7);
                                 i += rel;
+                                by_table = true;
                                 PF_CNT(5, 1);
                             } else {
                             const uint64_t lo = __ballot(LAv != 0);  // the window's bits (see DecShared::plav)
@@ -1264,12 +1324,73 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                         const uint64_t tq = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef DEC_PROF
+                        seq_publish(sh, sSeq, sFc, fm, i0, pos0, pos < 64u ? pos : 64u, lane, kw, &pf[16]);
+#else
                         seq_publish(sh, sSeq, sFc, fm, i0, pos0, pos < 64u ? pos : 64u, lane, kw);
+#endif
                         asm volatile("s_add_i32 %0, %0, 1" : "+s"(sSeq) : : "scc");  // (asm: keeps it in an SGPR)
 #ifdef DEC_PROF
                         pf[11] += __builtin_amdgcn_s_memtime() - tq;
 #endif
                         sP = Wb + pos;
+                        // A RUN of such windows.  What a window costs the walk is by now less its hops than what surrounds them --
+                        // the type mask of the 64 entries ahead (four cross-lane reads, a funnel shift), the window's row of
+                        // token lengths, the helper's progress -- and inside a stretch of the queue that is all type A none of
+                        // that is needed: the entries ahead of type A are counted once (`ones`, from the chunk masks in TAv),
+                        // and while 64 or more remain, a window is its table row and its slot: about thirty instructions.
+                        if (by_table && prev_table) {
+                            uint32_t ones = 0;
+                            {
+                                const uint32_t c2 = i >> 6, r2 = i & 63u;
+                                if (c2 >= blk0 && c2 < blk0 + 64u) {
+                                    const uint64_t c0 = readlane64(TAv, c2 - blk0) >> r2;
+                                    const bool all0 = c0 == (~0ull >> r2);
+                                    ones = all0 ? 64u - r2 : (uint32_t)__builtin_ctzll(~c0);
+                                    const uint32_t L1 = c2 - blk0 + 1u;
+                                    if (all0 && L1 < 64u) {
+                                        const uint64_t full = __ballot(TAv == ~0ull) >> L1;  // the chunks behind, all type A?
+                                        const uint32_t nf = (uint32_t)__builtin_ctzll(~full);   // (<= 64 - L1: the shift brought zeros in)
+                                        ones += 64u * nf;
+                                        if (L1 + nf < 64u) ones += (uint32_t)__builtin_ctzll(~readlane64(TAv, L1 + nf));  // (not all ones)
+                                    }
+                                }
+                            }
+                            uint32_t rp0 = pos - 64u, rkw = kw + 1u, rWb = Wb + 64u;
+#ifdef DEC_PROF
+                            const uint64_t trl = __builtin_amdgcn_s_memtime();
+#endif
+                            while (ones >= 64u && rWb + 64u <= sNb) {
+                                if (rkw >= tknown) {
+                                    tknown = RFL(lds_load(&sh.tprog));
+                                    if (rkw >= tknown) { PF_CNT(15, 1); break; }  // (the helper is not there yet: the walk above waits for it and hops)
+                                }
+                                const uint32_t rs = rkw % DEC_PREP, tl = lane < 9u ? lane : 0u;
+                                const uint64_t tfm = sh.tabfm[rs][tl];
+                                const uint32_t tce = sh.tabce[rs][tl];
+                                const uint64_t fm2 = readlane64(tfm, rp0);
+                                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)rp0);
+#ifdef DEC_PROF
+                                seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw, &pf[16]);
+#else
+                                seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw);
+#endif
+                                asm volatile("s_add_i32 %0, %0, 1" : "+s"(sSeq) : : "scc");
+                                const uint32_t cnt = ce & 0x7Fu;
+                                i += cnt;
+                                ones -= cnt;
+                                rp0 = ce >> 7;
+                                rkw += 1u;
+                                rWb += 64u;
+                                PF_CNT(5, 1);
+                                PF_CNT(17, 1);
+                            }
+#ifdef DEC_PROF
+                            pf[14] += __builtin_amdgcn_s_memtime() - trl;
+#endif
+                            sP = rWb + rp0;
+                        }
+                        prev_table = by_table;
                         // exit test, once per window: queue exhausted (i == sCur) or stream exhausted (sP >= sNb); one sign
                         // test (all quantities are below 2^31) instead of two compare / select pairs
                         if ((int32_t)((sCur - 1u - i) | (sNb - 1u - sP)) < 0) break;
@@ -1294,7 +1415,7 @@ void k_decode(DecArgs a) {
                 }
                 PF_ADD(2);
                 __syncthreads();
-                if (threadIdx.x == 0) { sh.pprog = 0; sh.sprog = 0; }  // between the two barriers that end the phase
+                if (threadIdx.x == 0) { sh.pprog = 0; sh.sprog = 0; sh.tprog = 0; }  // between the two barriers that end the phase
                 phase++;
                 PF_CNT(8, 1);
                 const uint32_t seq_end = sh.head;
@@ -1389,10 +1510,29 @@ void k_decode(DecArgs a) {
                             const uint32_t q = atomicAdd(&sh.ndup, 1u);
                             if (q < a.caps.lis) q0[q] = t0 + u * STR;
                         } else {
+#ifdef EXP_BUCKET  // TIMING EXPERIMENT (round 4, wrong results): what the decoder's stores would cost as appends to per-tile lists
+                            // (a cell of a level-1 band: an 8-byte store to one of 64 slots of its tile's 512-byte stretch -- 2025 hot
+                            // stretches per image instead of 41 000 cold lines; no unscatter behind)
+                            const uint32_t cidx = ix[u] & IDXM;
+                            uint32_t ck, ci, cj;
+                            decomp(g, cidx, ck, ci, cj);
+                            const bool l1c = a.fl.p && !((int)ci < a.fl.off_h && (int)cj < a.fl.off_w);
+                            if (l1c) {
+                                const uint32_t bi = (int)ci >= a.fl.off_h ? ci - (uint32_t)a.fl.off_h : ci, bj = (int)cj >= a.fl.off_w ? cj - (uint32_t)a.fl.off_w : cj;
+                                const uint32_t tyx = min(bi / (IW_TH / 2), (uint32_t)a.fl.gy - 1u) * (uint32_t)a.fl.gx + min(bj / (IW_TW / 2), (uint32_t)a.fl.gx - 1u);
+                                int2 *pl = reinterpret_cast<int2 *>(out + (size_t)ck * g.hw) + (size_t)tyx * 64u + ((t0 + u * STR) & 63u);
+                                *pl = make_int2((int)cidx, v[u]);
+                            } else {
+                                out[cidx] = v[u];
+                            }
+#else
                             out[ix[u] & IDXM] = v[u];
+#endif
                         }
                         // (every entry with a value, those of duplicated cells included: a set word only means "read")
+#ifndef EXP_NOFLAG  // (TIMING EXPERIMENT, with EXP_BUCKET: no tile is marked -- the inverse level 1 reads no detail band at all)
                         if (mark) l1_mark(g, a.fl, plane0, ix[u] & IDXM);
+#endif
                     }
                 }
             };
@@ -1422,7 +1562,7 @@ void k_decode(DecArgs a) {
             if (ecode) atomicOr(a.err, ecode);
 #ifdef DEC_PROF
             PF_ADD(9);
-            if (b == 0) for (int q = 0; q < 14; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 ? pf[q] : (pf[q] >> 10));
+            if (b == 0) for (int q = 0; q < 18; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q == 17 ? pf[q] : (pf[q] >> 10));
 #endif
         }
         __syncthreads();
@@ -1439,6 +1579,9 @@ void k_decode(DecArgs a) {
 #define UNSC_BLOCKS 8
 #endif
 __global__ __launch_bounds__(256) void k_unscatter(DecArgs a) {
+#ifdef EXP_BUCKET
+    return;
+#endif
     const uint32_t slot = blockIdx.x / UNSC_BLOCKS, part = blockIdx.x % UNSC_BLOCKS;
     const uint32_t cnt = a.lsp_count[slot];
     const uint32_t *idx = a.lsp_idx + (size_t)slot * a.caps.lsp;

@@ -1206,6 +1206,8 @@ __global__ __launch_bounds__(DW_BLOCK) void k_idwt_level_pf(IdwtKArgs a, uint32_
     __shared__ uint32_t s_next[2];
     uint32_t *const myctr = ctr + 32u * x;
     const uint32_t cbase = cb.v[x];
+    // "on a CU": who waits for this launch to be resident before launching a neighbour (spiht_ctx_wait_resident) counts these
+    if (tid == 0) atomicAdd(ctr + TILECTR_STARTED, 1u);
     uint32_t k, kn;  // position in the XCD's range of the tile being worked on / of the one after
     if (tid == 0) {
         s_next[0] = atomicAdd(myctr, 1u) - cbase;
@@ -1571,14 +1573,16 @@ static int launch_idwt_FM(IdwtKArgs a, int planes, hipStream_t st, TileCtr *tc) 
             // XCD x draws one number per tile of its range and two more per workgroup (the look-ahead past the end)
             tc->base[x] += (nt >> 3) + (x < (nt & 7u) ? 1u : 0u) + 2u * ((G + 7u - x) >> 3);
         }
+        tc->started += G;
         if (a.first) hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, true>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb);
         else if (a.flags && (uint64_t)a.enc_h * a.enc_w * 4u < (1ull << 31))
             hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false, true>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb);
         else { a.flags = nullptr; hipLaunchKernelGGL((k_idwt_level_pf<F, LOM, HIM, false>), dim3(G), dim3(DW_BLOCK), pad, st, a, gx, gy, ctr, cb); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) {  // the launch did not happen: counters and book-keeping start over together
-            (void)hipMemsetAsync(tc->dev, 0, 8 * 32 * sizeof(uint32_t), st);
+            (void)hipMemsetAsync(tc->dev, 0, TILECTR_WORDS * sizeof(uint32_t), st);
             for (uint32_t x = 0; x < 8; x++) tc->base[x] = 0;
+            tc->started = 0;
         }
         return (int)e;
     }

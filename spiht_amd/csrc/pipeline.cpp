@@ -52,7 +52,6 @@ struct spiht_pipeline {
     // colour model of the coded pictures (spiht_pipeline_set_color3): the pipeline's own, put on the H context around its calls
     bool color_on = false;
     double cAf[9], cMf[9], cAi[9], cMi[9], cpf = 1.0, cpi = 1.0;
-    uint32_t gap_us = 100;
     int poisoned = SPIHT_OK;   // a call failed half-way: the schedule's state is void, every later call returns this
     const double *mp() const { return mults.empty() ? nullptr : mults.data(); }
 };
@@ -158,11 +157,6 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
         if (st == SPIHT_OK && a_h > 0 && a_w > 0 && mode != SPIHT_MODE_PERIODIZATION)
             st = spiht_dev_alloc(p->Hc, (uint64_t)B * c * a_h * a_w * 8, (void **)&p->approx);
     }
-    p->gap_us = 0;
-    if (const char *e = getenv("SPIHT_EXP_GAP_US")) {  // EXPERIMENT (round 4, to be removed): the timer the LDS pad replaces
-        const long v = atol(e);
-        p->gap_us = (uint32_t)(v < 0 ? 0 : v > 10000 ? 10000 : v);
-    }
     if (st == SPIHT_OK) st = spiht_ctx_synchronize(p->Hc);
     if (st != SPIHT_OK) { pipeline_free(p); return st; }
     *out = p;
@@ -261,29 +255,35 @@ static int submit_impl(spiht_pipeline *p, const double *d_img, uint8_t *d_out, u
     const uint8_t *x_maxn = d_max_n;
     if (comm) {  // the one exchange of a multi-GPU job, on the list-coding stream; the decoder reads this rank's gathered rows
         CHK(spiht_gather_streams(L, comm, d_out, d_nbits, d_max_n, p->B, p->slot_stride, d_all_slots, d_all_nbits, d_all_max_n));
-        x_out = d_all_slots + (uint64_t)rank * p->B * p->slot_stride;
-        x_nbits = d_all_nbits + (uint64_t)rank * p->B;
-        x_maxn = d_all_max_n + (uint64_t)rank * p->B;
+        int world = 0;
+        CHK(spiht_comm_info(comm, &world, nullptr, nullptr));
+        uint64_t o_s = 0, o_n = 0, o_m = 0;
+        CHK(spiht_gather_row_offsets(rank, world, p->B, p->slot_stride, &o_s, &o_n, &o_m));
+        x_out = d_all_slots + o_s;
+        x_nbits = (const uint64_t *)((const uint8_t *)d_all_nbits + o_n);
+        x_maxn = d_all_max_n + o_m;
     }
     CHK(spiht_nbits_to_nbytes(L, x_nbits, p->B, p->nbytes[s]));
-    // H: the coarse levels of the previous batch's inverse transform (beside this batch's encoder) ...
+    // H: the previous batch's inverse transform, in two parts: the coarse levels (beside this batch's encoder) and level 1 ...
     if (p->pending) {
         CHK(queue_inverse_coarse(p, p->pending_slot));
-        CHK(spiht_ctx_wait_event(L, p->ev_c));  // ... this batch's decoder not before they are through,
-        // and a little later still: level 1's persistent workgroups (three per CU, launched at that moment) should have
-        // settled evenly before the decoder's arrive -- dispatched in the same microseconds, some CUs end up with four of
-        // them and no room for a decoder workgroup until the whole level is through (decoder 13.9 instead of 10 ms)
-        CHK(spiht_ctx_pause_us(L, p->gap_us));
+        CHK(queue_inverse_level1(p, p->pending_slot, p->pending_out));
+        p->pending = false;
+        // ... L: this batch's decoder not before the coarse levels are through, and not before level 1's persistent workgroups
+        // (three per CU, too large for a fourth: dwt.hip) are on the CUs: a CU serves its older wavefronts first, the inverse
+        // level 1 beside a decoder that got there first takes 4.4 instead of 3.7 ms, and decoder workgroups that arrive
+        // TOGETHER with it land unevenly (12.5 instead of 8.8 ms for the decoder, round 4).  The wait is for that fact, not for
+        // a time: a one-wavefront kernel on L that watches the count of started workgroups (spiht_ctx_wait_resident).
+        const void *ctr = nullptr;
+        uint32_t target = 0;
+        CHK(spiht_ctx_resident_ticket(p->Hc, &ctr, &target));
+        CHK(spiht_ctx_wait_event(L, p->ev_c));
+        CHK(spiht_ctx_wait_resident(L, ctr, target, 1000));
     }
     CHK(spiht_decode_lists_flags_batch_i32(L, x_out, p->slot_stride, p->nbytes[s], x_maxn, p->B, p->c, p->H, p->W, p->wavelet,
                                            p->mode, p->level, p->rec[s], p->flags[s]));
     CHK(spiht_event_record(p->ev_d[s], L));
     p->used[s] = true;
-    // H: ... and its level 1 (beside this batch's decoder, and there first)
-    if (p->pending) {
-        CHK(queue_inverse_level1(p, p->pending_slot, p->pending_out));
-        p->pending = false;
-    }
     p->pending = true;
     p->pending_slot = s;
     p->pending_out = d_img_out;

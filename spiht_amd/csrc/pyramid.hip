@@ -349,15 +349,18 @@ extern "C" int spiht_launch_pyramid(const Geom *g, int B, const int32_t *d_x, ui
     return (int)hipGetLastError();
 }
 
-// One wavefront that does nothing for about `ticks` shader clocks (spiht_ctx_pause_us): spacing between the kernels of two
-// contexts when the order in which their workgroups reach the CUs matters (csrc/pipeline.cpp).
-__global__ __launch_bounds__(64) void k_pause(uint64_t ticks) {
+// One wavefront that waits until a counter in device memory has reached `target` (arithmetic modulo 2^32) -- or gives up
+// after `ticks` shader clocks: what is queued behind it on its stream starts when the workgroups that raise the counter are
+// on the CUs (spiht_ctx_wait_resident; csrc/pipeline.cpp launches the list decoder behind the persistent workgroups of the
+// inverse transform's level 1 that way).
+__global__ __launch_bounds__(64) void k_gate(const uint32_t *counter, uint32_t target, uint64_t ticks) {
     const uint64_t t0 = __builtin_amdgcn_s_memtime();
-    uint32_t guard = 0;
-    while (__builtin_amdgcn_s_memtime() - t0 < ticks && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(16);
+    while ((int32_t)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0 &&
+           __builtin_amdgcn_s_memtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(8);
 }
-extern "C" int spiht_launch_pause(uint64_t ticks, hipStream_t st) {
-    hipLaunchKernelGGL(k_pause, dim3(1), dim3(64), 0, st, ticks);
+extern "C" int spiht_launch_gate(const uint32_t *counter, uint32_t target, uint64_t ticks, hipStream_t st) {
+    hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, counter, target, ticks);
     return (int)hipGetLastError();
 }
 

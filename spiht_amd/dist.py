@@ -210,6 +210,11 @@ class HostGroup:
         out = self._exchange(struct.pack("<d", float(value)), lambda parts: struct.pack("<d", max(struct.unpack("<d", p)[0] for p in parts)))
         return struct.unpack("<d", out)[0]
 
+    def allgather(self, value):
+        """every rank's double, in rank order, on every rank"""
+        out = self._exchange(struct.pack("<d", float(value)), lambda parts: b"".join(parts))
+        return [v[0] for v in struct.iter_unpack("<d", out)]
+
     def bcast(self, payload=None):
         """rank 0's payload to every rank"""
         return self._exchange(payload if self.rank == 0 else b"", lambda parts: parts[0])

@@ -161,9 +161,10 @@ def _group_worker(rank, world, port, q):
         m = g.max(rank * 1.5)
         b = g.bcast(bytes(range(128)) if rank == 0 else None)
         m2 = g.max(-float(rank))
+        ag = g.allgather(10.0 + rank)
         g.barrier()
         g.close()
-        q.put((rank, m, m2, b == bytes(range(128))))
+        q.put((rank, m, m2, b == bytes(range(128)) and ag == [10.0 + r for r in range(world)]))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
 
@@ -182,6 +183,36 @@ def test_host_group_barrier_max_bcast():
     for p in procs:
         p.join(timeout=60)
     assert res == [(r, 4.5, 0.0, True) for r in range(world)], res
+
+
+def test_gathered_rows_of_every_rank_world_8():
+    """spiht_pipeline_submit_gather hands the decoder of rank r its rows of the GATHERED arrays: spiht_gather_row_offsets is
+    that arithmetic, on its own (no device).  World 8 on fake buffers laid out as the all-gather leaves them (rank-major,
+    spiht_amd/dist.py): every rank's offsets select exactly the slots / bit counts / start planes that rank contributed,
+    and out-of-range arguments are refused."""
+    import ctypes as C
+    from spiht_amd import _lib
+    L = _lib.lib()
+    world, B, slot = 8, 256, 129600
+    rng = np.random.default_rng(5)
+    own = [(rng.integers(0, 256, (B, slot), dtype=np.uint8), rng.integers(0, 1 << 40, B).astype(np.uint64),
+            rng.integers(0, 31, B).astype(np.uint8)) for _ in range(2)]  # (two distinct shards are enough to tell rows apart)
+    shard = lambda r: own[r & 1]  # noqa: E731
+    all_slots = np.concatenate([shard(r)[0] for r in range(world)]).reshape(-1)
+    all_nbits = np.concatenate([shard(r)[1] for r in range(world)])
+    all_maxn = np.concatenate([shard(r)[2] for r in range(world)])
+    for r in range(world):
+        o = [C.c_uint64() for _ in range(3)]
+        assert L.spiht_gather_row_offsets(r, world, B, slot, *[C.byref(v) for v in o]) == 0
+        os_, on, om = (int(v.value) for v in o)
+        assert (os_, on, om) == (r * B * slot, r * B * 8, r * B)
+        assert np.array_equal(all_slots[os_:os_ + B * slot].reshape(B, slot), shard(r)[0])
+        assert np.array_equal(all_nbits.view(np.uint8)[on:on + 8 * B].view(np.uint64), shard(r)[1])
+        assert np.array_equal(all_maxn[om:om + B], shard(r)[2])
+    o = [C.c_uint64() for _ in range(3)]
+    for bad in ((8, 8), (-1, 8), (0, 0)):
+        assert L.spiht_gather_row_offsets(bad[0], bad[1], B, slot, *[C.byref(v) for v in o]) != 0
+    assert L.spiht_gather_row_offsets(1, 2, 1 << 40, 1 << 40, *[C.byref(v) for v in o]) != 0  # overflow
 
 
 def _job_worker(job, rank, world, port, q):

@@ -11,6 +11,7 @@ for ln in sys.stdin:
         d = json.loads(ln)
         print('ms_per_step', d['ms_per_step'], 'bit-exact', d['check'].get('stream_bit_exact_vs_oracle'), d['check'].get('decoded_image_bit_exact_vs_oracle'), d['check'].get('nbits_all_equal_budget'))
         print(json.dumps(d.get('stages_ms_per_step_summed_over_streams')))
+        print(json.dumps(d.get('single_image_latency')))
 " >> $out
 done
 grep -v "synthesised" $out
