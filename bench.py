@@ -440,7 +440,9 @@ def main():
             tm = ctx.timing()
             a_ms = {k2: v2[0] / v2[1] for k2, v2 in tm.items() if v2[1] and k2 in ("dwt_level1", "idwt_level1", "pyramid")}
             if "dwt_level1" in a_ms:
-                alone = {"dwt_level1_ms": round(a_ms["dwt_level1"], 4),
+                # (the pipeline leaves nothing on `ctx` between its calls: these are the library's single-call settings)
+                alone = {"context_options": {k2: ctx.get_option(k2) for k2 in ("idwt_groups", "pads_persist", "l1_flags")},
+                         "dwt_level1_ms": round(a_ms["dwt_level1"], 4),
                          "dwt_level1_frac": round(dwt_bytes / (a_ms["dwt_level1"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "idwt_level1_ms": round(a_ms.get("idwt_level1", float("nan")), 4),
                          "pyramid_ms": round(a_ms.get("pyramid", float("nan")), 4)}

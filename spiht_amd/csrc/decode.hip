@@ -831,12 +831,7 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
         // with that walk, which they do after a token or two (the code synchronises itself).  Same token lengths as plav
         // above: 5 + the significant ones among the four offspring that follow.  Behind the announcement of the batch: the
         // sequencer never waits for a table, it hops through a window whose table is not there yet.
-#ifndef DEC_NO_TABLE  // EXPERIMENT (round 4): A/B without the tables
-        if ((j & DEC_PREP_B) != 0)
-#else
-        if (false)
-#endif
-        {
+        if ((j & DEC_PREP_B) != 0) {
             static_assert(DEC_PREP_B == 16 && DEC_PREP % 32 == 0, "two batches = the 32 windows of a table pass");
             const uint32_t tb = j - DEC_PREP_B, uw = lane & 31u, hf = lane >> 5;
             const uint64_t *wb = sh.wbits[(tb + uw) % (DEC_PREP + DEC_RING)];
@@ -1010,9 +1005,6 @@ void k_decode(DecArgs a) {
         // its SIMD it must not queue for issue slots behind them
 #ifndef DEC_SEQ_NOPRIO
         if (wave == 0) __builtin_amdgcn_s_setprio(3);
-#ifdef DEC_HELPER_PRIO  // EXPERIMENT (round 4)
-        if (wave == 1) __builtin_amdgcn_s_setprio(DEC_HELPER_PRIO);
-#endif
 #endif
         bool done = bad;
         for (; !done; --n) {
@@ -1510,29 +1502,10 @@ void k_decode(DecArgs a) {
                             const uint32_t q = atomicAdd(&sh.ndup, 1u);
                             if (q < a.caps.lis) q0[q] = t0 + u * STR;
                         } else {
-#ifdef EXP_BUCKET  // TIMING EXPERIMENT (round 4, wrong results): what the decoder's stores would cost as appends to per-tile lists
-                            // (a cell of a level-1 band: an 8-byte store to one of 64 slots of its tile's 512-byte stretch -- 2025 hot
-                            // stretches per image instead of 41 000 cold lines; no unscatter behind)
-                            const uint32_t cidx = ix[u] & IDXM;
-                            uint32_t ck, ci, cj;
-                            decomp(g, cidx, ck, ci, cj);
-                            const bool l1c = a.fl.p && !((int)ci < a.fl.off_h && (int)cj < a.fl.off_w);
-                            if (l1c) {
-                                const uint32_t bi = (int)ci >= a.fl.off_h ? ci - (uint32_t)a.fl.off_h : ci, bj = (int)cj >= a.fl.off_w ? cj - (uint32_t)a.fl.off_w : cj;
-                                const uint32_t tyx = min(bi / (IW_TH / 2), (uint32_t)a.fl.gy - 1u) * (uint32_t)a.fl.gx + min(bj / (IW_TW / 2), (uint32_t)a.fl.gx - 1u);
-                                int2 *pl = reinterpret_cast<int2 *>(out + (size_t)ck * g.hw) + (size_t)tyx * 64u + ((t0 + u * STR) & 63u);
-                                *pl = make_int2((int)cidx, v[u]);
-                            } else {
-                                out[cidx] = v[u];
-                            }
-#else
                             out[ix[u] & IDXM] = v[u];
-#endif
                         }
                         // (every entry with a value, those of duplicated cells included: a set word only means "read")
-#ifndef EXP_NOFLAG  // (TIMING EXPERIMENT, with EXP_BUCKET: no tile is marked -- the inverse level 1 reads no detail band at all)
                         if (mark) l1_mark(g, a.fl, plane0, ix[u] & IDXM);
-#endif
                     }
                 }
             };
@@ -1579,9 +1552,6 @@ void k_decode(DecArgs a) {
 #define UNSC_BLOCKS 8
 #endif
 __global__ __launch_bounds__(256) void k_unscatter(DecArgs a) {
-#ifdef EXP_BUCKET
-    return;
-#endif
     const uint32_t slot = blockIdx.x / UNSC_BLOCKS, part = blockIdx.x % UNSC_BLOCKS;
     const uint32_t cnt = a.lsp_count[slot];
     const uint32_t *idx = a.lsp_idx + (size_t)slot * a.caps.lsp;
