@@ -82,6 +82,26 @@ def load_image(seed):
     return synth_image(seed, C_IMG, H, W)
 
 
+def _nproc():
+    """CPUs this process may use: its affinity mask, cut by the cgroup's CPU quota where there is one (what `nproc` and a
+    container's share say) -- the all-cores CPU leg runs one independent image per such CPU."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def digest(a):
     """order-independent-free checksum of an array's bytes: (wrapping sum, xor) of its 64-bit words"""
     b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
@@ -584,7 +604,7 @@ def main():
             if args.cpu_cores != 1 and pix == np.float64:
                 import concurrent.futures as cf
                 import multiprocessing as mp
-                nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+                nproc = _nproc()
                 ncores = max(2, min(args.cpu_cores if args.cpu_cores > 0 else nproc, nproc, nd, 512))
                 jobs = [(seeds[k::ncores], 1) for k in range(ncores) if seeds[k::ncores]]
                 with cf.ProcessPoolExecutor(max_workers=ncores, mp_context=mp.get_context("spawn")) as ex:

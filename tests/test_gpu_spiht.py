@@ -142,6 +142,36 @@ def test_decode_arbitrary_bytes(oracle):
             _check_decode(oracle, d, 6, (c, h, w), lh, lw)
 
 
+def test_decode_long_stretches_of_one_entry_type(oracle):
+    """The LIS walk looks a 64-bit window up instead of hopping through it when the 64 queue entries it can meet are all
+    type A (decode.hip: DecShared::tabfm, the helper's walks from the nine entry points), and takes runs of such windows in
+    a loop of its own.  Medium and large arrays whose queues have long stretches of one type (profiles/
+    r04_lis_type_runs.txt), under byte strings no encoder made, with few, some, half and mostly ones -- every entry point,
+    the merges of the helper's walks, windows with no fired entry and windows full of them, runs that end at the end of the
+    queue, of a chunk block (4096 entries) and of the stream -- and under encoder streams cut at many lengths; both widths
+    of the decoder."""
+    from spiht_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(31)
+    geoms = [(3, 300, 420, 5, 7), (1, 512, 512, 4, 4), (3, 345, 287, 11, 9), (2, 640, 520, 10, 9)]
+    try:
+        for waves in (12, 8):
+            ctx.set_decoder_waves(waves)
+            for gi, (c, h, w, lh, lw) in enumerate(geoms):
+                for p1 in (0.02, 0.08, 0.25, 0.5, 0.8):
+                    ln = int(rng.integers(3000, 60000))
+                    bits = (rng.random(8 * ln) < p1).astype(np.uint8)
+                    d = np.packbits(bits, bitorder="little").tobytes()
+                    for n in (11, 5):
+                        _check_decode(oracle, d, n, (c, h, w), lh, lw)
+                x = synth_coeffs(50 + gi, c, h, w, lh, lw, scale=float(10 ** rng.uniform(2.5, 4.5)))
+                d, n = oracle.encode(x, lh, lw, min(8 * c * h * w, 600000))
+                for cut in sorted({len(d), len(d) // 2, len(d) // 3 + 1, len(d) // 7, int(rng.integers(1, len(d)))}):
+                    _check_decode(oracle, d[:cut], n, (c, h, w), lh, lw)
+    finally:
+        ctx.set_decoder_waves(12)
+
+
 def test_decoder_with_eight_wavefronts(oracle):
     """The 8-wavefront build of the decoder (spiht_ctx_set_decoder_waves: the list-coding contexts of the pipelined
     schedule use it) decodes what the 12-wavefront one does: encoder streams, their prefixes, arbitrary bytes on trees
