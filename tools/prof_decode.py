@@ -73,4 +73,4 @@ for k, nm in enumerate(names):
         print("%-12s %d" % (nm, w[k]))
     else:
         print("%-12s %8.3f Mcycles (%.1f%%)" % (nm, w[k] * 1024 / 1e6, 100.0 * w[k] / max(tot, 1)))
-print("total %.3f Mticks (s_memtime ticks; 100 MHz => %.2f ms)" % (tot * 1024 / 1e6, tot * 1024 / 1e5 / 1e3))
+print("total %.3f Mcycles of the sequencer wavefront (s_memtime: shader clocks, 2.1-2.4 GHz => about %.2f ms)" % (tot * 1024 / 1e6, tot * 1024 / 2.4e9 * 1e3))
