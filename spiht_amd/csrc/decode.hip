@@ -344,35 +344,33 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
-// Ring space, checked once per half ring: before item `seq` (a multiple of RING/2 -- fc counts the publishes down to it) every
-// item below seq - RING/2 must have been consumed.  Also tells the helper which of ITS ring entries are free (windows before kw).
-__device__ __forceinline__ void seq_ring_check(DecShared &sh, uint32_t seq, uint32_t &fc, uint32_t lane, uint32_t kw, uint64_t *pfw) {
-    constexpr uint32_t HALF = DEC_RING / 2;
-    fc = HALF;
-    if (lane == 0) __hip_atomic_store(&sh.sprog, kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (seq >= DEC_RING) {
-        const uint32_t lim = seq - HALF;  // items [0, lim) must be done
-        // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
-        const uint32_t w = lane < DEC_NWK ? lane : 0u;
-        const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
-        uint32_t spins = 0;
-#ifdef DEC_PROF
-        const uint64_t tws = __builtin_amdgcn_s_memtime();
-#endif
-        while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
-        }
-#ifdef DEC_PROF
-        if (pfw) *pfw += __builtin_amdgcn_s_memtime() - tws;
-#endif
-    }
-}
-
 __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_t &fc, uint64_t fm, uint32_t e_start,
                                             uint32_t pos0, uint32_t pos1, uint32_t lane, uint32_t kw, uint64_t *pfw = nullptr) {
-    // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of RING/2
-    if (fc == 0) seq_ring_check(sh, seq, fc, lane, kw, pfw);
+    constexpr uint32_t HALF = DEC_RING / 2;
+    // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of HALF
+    if (fc == 0) {
+        fc = HALF;
+        // the helper's ring entries of the windows before this one are free (announced here, every HALF windows,
+        // rather than with a test of its own per window)
+        if (lane == 0) __hip_atomic_store(&sh.sprog, kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (seq >= DEC_RING) {
+            const uint32_t lim = seq - HALF;  // items [0, lim) must be done
+            // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
+            const uint32_t w = lane < DEC_NWK ? lane : 0u;
+            const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
+            uint32_t spins = 0;
+#ifdef DEC_PROF
+            const uint64_t tws = __builtin_amdgcn_s_memtime();
+#endif
+            while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
+            }
+#ifdef DEC_PROF
+            if (pfw) *pfw += __builtin_amdgcn_s_memtime() - tws;
+#endif
+        }
+    }
     asm volatile("s_add_i32 %0, %0, -1" : "+s"(fc) : : "scc");  // (asm: keeps the counter in an SGPR)
     if (lane == 0) {
         Slot *slot = &sh.ring[seq % DEC_RING];
@@ -961,7 +959,7 @@ void k_decode(DecArgs a) {
         uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
 #ifdef DEC_PROF
-        uint64_t pf[19] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t pf[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1223,7 +1221,7 @@ void k_decode(DecArgs a) {
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
-                        bool by_table = false, none_a = false;
+                        bool by_table = false;
 #ifdef DEC_PROF
                         const uint64_t th = __builtin_amdgcn_s_memtime();
                         pf[12] += th - tw;
@@ -1246,7 +1244,6 @@ void k_decode(DecArgs a) {
                             // most: true of every window but a phase's first): the helper has walked it for that entry point
                             // already (DecShared::tabfm) -- one look-up instead of a hop per fired entry.  Four windows of
                             // five on a 4096 x 4096 picture, one of two at 1080p (profiles/r04_lis_type_runs.txt).
-                            none_a = Tr == 0ull;  // (the hop loop below shifts Tr)
                             if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw >= tknown) tknown = RFL(lds_load(&sh.tprog));
                             if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw < tknown) {
                                 const uint32_t tl = lane < 9u ? lane : 0u;
@@ -1386,61 +1383,6 @@ void k_decode(DecArgs a) {
                             sP = rWb + rp0;
                         }
                         prev_table = by_table;
-                        // The other kind of stretch: NO entry ahead is a type-A entry with offspring (type B entries, and the
-                        // type-A entries of nodes without offspring, which cannot fire): every one of them takes exactly one
-                        // bit whatever the bit is, so a window is 64 entries and nothing else -- no table, no walk.  Once a
-                        // window has gone that way and ended on the window boundary, the entries of that kind still ahead are
-                        // counted (chunk masks again, never past the queue's end), and the windows they fill are published
-                        // up to 32 at a time, one per lane: fired mask 0, first entry i + 64 l.  (A third of the list entries are
-                        // of this kind, nearly all of them in stretches of 64 and more: profiles/r04_lis_type_runs.txt.)
-                        if (none_a && pos == 64u && vb == 64u && i < sCur) {
-                            uint32_t zeros = 0;
-                            {
-                                const uint32_t c2 = i >> 6, r2 = i & 63u;
-                                if (c2 >= blk0 && c2 < blk0 + 64u) {
-                                    const uint64_t c0 = readlane64(TAv, c2 - blk0) >> r2;  // (the shift brings zeros in: capped below)
-                                    zeros = c0 == 0ull ? 64u - r2 : (uint32_t)__builtin_ctzll(c0);
-                                    const uint32_t L1 = c2 - blk0 + 1u;
-                                    if (c0 == 0ull && L1 < 64u) {
-                                        const uint64_t nonz = __ballot(TAv != 0ull) >> L1;  // the chunks behind: any type-A entry?
-                                        const uint32_t nz = nonz ? (uint32_t)__builtin_ctzll(nonz) : 64u - L1;
-                                        zeros += 64u * nz;
-                                        if (L1 + nz < 64u) zeros += (uint32_t)__builtin_ctzll(readlane64(TAv, L1 + nz));  // (not zero)
-                                    }
-                                }
-                                zeros = min(zeros, sCur - i);  // (chunks past the queue's end read as zeros too)
-                            }
-                            uint32_t rkw = kw + 1u, rWb = Wb + 64u;
-                            while (zeros >= 64u && rWb + 64u <= sNb) {
-                                // the workers take a window's bits from the helper's ring: only windows it has prepared
-                                if (rkw >= pknown) {
-                                    pknown = RFL(lds_load(&sh.pprog));
-                                    if (rkw >= pknown) break;
-                                }
-                                if (sFc == 0u) {
-#ifdef DEC_PROF
-                                    seq_ring_check(sh, sSeq, sFc, lane, rkw, &pf[16]);
-#else
-                                    seq_ring_check(sh, sSeq, sFc, lane, rkw, nullptr);
-#endif
-                                }
-                                const uint32_t nW = min(min(32u, zeros >> 6), min(min((sNb - rWb) >> 6, pknown - rkw), sFc));
-                                if (lane < nW) {
-                                    Slot *slot = &sh.ring[(sSeq + lane) % DEC_RING];
-                                    *reinterpret_cast<uint4 *>(slot) = make_uint4(0u, 0u, i + 64u * lane, 64u << 8);
-                                    asm volatile("" ::: "memory");  // (one wavefront's LDS writes stay in order: the slot before its flag)
-                                    __hip_atomic_store(&slot->ready, sSeq + lane + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                }
-                                asm volatile("s_add_i32 %0, %0, %1" : "+s"(sSeq) : "s"(nW) : "scc");
-                                asm volatile("s_sub_i32 %0, %0, %1" : "+s"(sFc) : "s"(nW) : "scc");
-                                i += 64u * nW;
-                                zeros -= 64u * nW;
-                                rkw += nW;
-                                rWb += 64u * nW;
-                                PF_CNT(18, nW);
-                            }
-                            sP = rWb;
-                        }
                         // exit test, once per window: queue exhausted (i == sCur) or stream exhausted (sP >= sNb); one sign
                         // test (all quantities are below 2^31) instead of two compare / select pairs
                         if ((int32_t)((sCur - 1u - i) | (sNb - 1u - sP)) < 0) break;
@@ -1593,7 +1535,7 @@ void k_decode(DecArgs a) {
             if (ecode) atomicOr(a.err, ecode);
 #ifdef DEC_PROF
             PF_ADD(9);
-            if (b == 0) for (int q = 0; q < 19; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q == 17 || q == 18 ? pf[q] : (pf[q] >> 10));
+            if (b == 0) for (int q = 0; q < 18; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q == 17 ? pf[q] : (pf[q] >> 10));
 #endif
         }
         __syncthreads();
