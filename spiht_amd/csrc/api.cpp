@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -2329,6 +2330,7 @@ struct HostPool {
     static constexpr size_t kMaxPooled = (size_t)1 << 30, kMaxOut = (size_t)4 << 30;
 };
 HostPool g_host_pool;
+bool g_host_pool_exiting = false;  // process exit: buffers are left to the system (the HIP runtime may be gone already)
 }  // namespace
 
 // bytes of page-locked host memory (usable from every device).  SPIHT_ERR_NOMEM when the allocation fails or more than
@@ -2337,6 +2339,8 @@ extern "C" int spiht_host_alloc(uint64_t bytes, void **h_ptr) {
     if (!h_ptr || bytes == 0) return SPIHT_ERR_ARG;
     *h_ptr = nullptr;
     HostPool &hp = g_host_pool;
+    static const int registered = atexit([] { g_host_pool_exiting = true; });
+    (void)registered;
     std::lock_guard<std::mutex> lk(hp.mu);
     if (hp.out + bytes > HostPool::kMaxOut) return SPIHT_ERR_NOMEM;
     int best = -1;
@@ -2375,7 +2379,7 @@ extern "C" int spiht_host_free(void *h_ptr) {
         hp.out -= b.cap;
         hp.free_list.push_back(b);
         hp.pooled += b.cap;
-        while (hp.pooled > HostPool::kMaxPooled || hp.free_list.size() > 8) {  // the oldest goes back to the system
+        while (!g_host_pool_exiting && (hp.pooled > HostPool::kMaxPooled || hp.free_list.size() > 8)) {  // the oldest goes back to the system
             (void)hipHostFree(hp.free_list.front().p);
             hp.pooled -= hp.free_list.front().cap;
             hp.free_list.erase(hp.free_list.begin());

@@ -654,6 +654,45 @@ def test_c_pipeline_matches_fused(cfg):
 
 
 @pytest.mark.gpu
+def test_returned_arrays_are_the_callers(oracle):
+    """decode_image / decode return NEW arrays (spiht_wrapper.py:192-216, lib.rs:35-42).  Here they are page-locked memory from
+    the library's pool (spiht_host_alloc): an array a caller still holds is never handed out again, one that was dropped is
+    (that is the point of the pool), and the arrays behave like any numpy array (writable, sliceable, survive arithmetic)."""
+    import gc
+    import spiht_amd
+    from spiht_amd import _lib
+    c, H, W, level, mb = 3, 360, 512, 4, 80000  # 4.4 MB per decoded picture: above result_array's 1 MB threshold
+    s = spiht_amd.SpihtSettings()
+    imgs = [synth_image(40 + k, c, H, W) for k in range(3)]
+    encs = [spiht_amd.encode_image(im, s, level, mb) for im in imgs]
+    refs = [oracle.decode_image(e.encoded_bytes, e.max_n, c, H, W, "bior2.2", level, 50.0, None) for e in encs]
+    held = [spiht_amd.decode_image(e, s) for e in encs]          # three arrays alive at once
+    ptrs = [a.ctypes.data for a in held]
+    assert len(set(ptrs)) == 3
+    for a, r in zip(held, refs):
+        assert a.dtype == np.float64 and a.flags.writeable and np.array_equal(a, r)
+    more = spiht_amd.decode_image(encs[0], s)                       # a fourth one while the three are held
+    assert more.ctypes.data not in ptrs and all(np.array_equal(a, r) for a, r in zip(held, refs))
+    view = held[1][:, 10:20]                                        # a view keeps its buffer alive
+    p1 = held[1].ctypes.data
+    held[1] = None
+    gc.collect()
+    again = spiht_amd.decode_image(encs[2], s)
+    assert again.ctypes.data != p1 and np.array_equal(view, refs[1][:, 10:20])
+    del view
+    gc.collect()
+    back = spiht_amd.decode_image(encs[2], s)                       # now the dropped buffer may come back (the pool's purpose)
+    assert np.array_equal(back, refs[2])
+    back += 1.0                                                     # in-place arithmetic on the caller's array
+    assert np.array_equal(back, refs[2] + 1.0) and np.array_equal(again, refs[2])
+    raw = spiht_amd.decode(encs[0].encoded_bytes, encs[0].max_n, c, *[oracle.geometry(H, W, "bior2.2", level)[k] for k in ("enc_h", "enc_w", "ll_h", "ll_w")])
+    assert raw.dtype == np.int32 and raw.flags.c_contiguous and raw.flags.writeable
+    big = _lib.result_array((2 << 20,), np.uint8)                   # the helper itself; small requests are ordinary arrays
+    small = _lib.result_array((100,), np.uint8)
+    assert big.shape == (2 << 20,) and small.shape == (100,)
+
+
+@pytest.mark.gpu
 def test_pipeline_leaves_nothing_on_a_borrowed_context(oracle):
     """spiht_pipeline_create_on runs the HBM-bound passes on the CALLER's context.  Its colour model and options are put on
     that context only while one of its calls queues work: after an IPT pipeline has run there, a plain 3-channel encode /
