@@ -38,7 +38,7 @@
 #define DEC_WK(wave) ((wave) - 2)
 #define DEC_IS_WORKER(wave) ((wave) >= 2)
 #define DEC_PREP 64   // windows the helper may run ahead of the sequencer (ring in LDS)
-#define DEC_PREP_B 16 // ... which it announces in batches of this many
+#define DEC_PREP_B 32 // ... which it prepares and announces in batches of this many (lane = (window, half))
 #ifndef DEC_RING
 #define DEC_RING 64   // windows in flight between sequencer and workers; a power of two (32 measured 4 % slower)
 #endif
@@ -125,10 +125,10 @@ struct DecShared {
             Slot ring[DEC_RING];
             Chain chain[DEC_RING];
             PhaseInfo ph;
-            // helper -> sequencer: per window position, the length a fired type-A entry would have if it started
-            // there; zero where the stream bit is 0 (an entry cannot fire there), so the window's bits are the
-            // ballot of "non-zero" and the sequencer reads nothing else
-            uint8_t plav[DEC_PREP][64];
+            // helper -> sequencer: per window, the length a fired type-A entry would have at each of its 64 positions, as
+            // three bit planes of (length - 5) and, fourth word, the window's bits themselves; the sequencer turns a row
+            // into one length per lane when it has to hop through the window (most windows it looks up, see tabfm)
+            uint64_t pln[DEC_PREP][4];
             // helper -> workers: the bits of each window and of the one after it (zero at and past the end of the
             // stream), so that a worker's window costs it no stream load.  A worker can lag DEC_RING windows behind the
             // sequencer, the helper run DEC_PREP ahead of it.
@@ -146,7 +146,7 @@ struct DecShared {
     uint32_t wfun[DEC_NW];      // per-wave carry functions
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     uint32_t pprog;             // windows of this phase the helper has prepared
-    uint32_t tprog;             // ... and walked under the all-type-A hypothesis (DecShared::tabfm): a multiple of 32
+    uint32_t tprog;             // ... and walked under the all-type-A hypothesis (DecShared::tabfm): announced a little later
     uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_RING/2 windows)
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
@@ -789,10 +789,22 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
     }
 }
 
-// helper loop of one LIS phase (wavefront 1): window j of the phase is stream window widx0 + j
+// helper loop of one LIS phase (wavefront 1): window j of the phase is stream window widx0 + j.  Batches of 32 windows, lane =
+// (window, half).  Token lengths first: the length of a fired type-A entry at position q is 5 + the significant ones among
+// the four offspring that follow ('0' or '1' + sign bit each) -- worked out for all 64 positions of the lane's window at once
+// with bitwise operations on 64-bit words (the k-th offspring's bit is one of the window shifted by k .. 2k-1, chosen by the
+// two-bit count of significant ones before it), which leaves (length - 5) as three bit planes: some 80 instructions for 32
+// windows where one lane per position took 40 per window (round 4: the helper, not the sequencer, set the decoder's pace in
+// long stretches of looked-up windows).  Then the window walked under the all-type-A hypothesis (DecShared::tabfm): from
+// entry point 0 in full -- a dozen steps at most, a fired entry takes five bits or more -- and four of the other eight entry
+// points (half 0: 1..4, half 1: 5..8) only until they fall in step with that walk, which they do after a token or two (the
+// code synchronises itself).  The windows are announced before their table (DecShared::pprog, tprog): the sequencer never waits
+// for a table, it hops through a window whose table is not there yet (a phase's first few).
 __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, uint32_t par, uint32_t widx0, uint32_t lane) {
-    uint64_t v = 0;         // 64 consecutive 64-bit stream words, one per lane (serves 63 windows)
-    uint32_t base = 0, have = 0;
+    static_assert(DEC_PREP_B == 32 && DEC_PREP % DEC_PREP_B == 0 && DEC_PREP >= 2 * DEC_PREP_B, "helper batches");
+    const uint32_t uw = lane & 31u, hf = lane >> 5;
+    // the words of the batch to come are fetched while the batch before is worked on
+    uint64_t nlo = stream_word64(bs, widx0 + uw), nhi = stream_word64(bs, widx0 + uw + 1u);
     for (uint32_t j = 0;; j += DEC_PREP_B) {
         uint32_t spins = 0;
         for (;;) {  // room for another batch, or the end of the phase
@@ -801,96 +813,73 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) { sh.bad = 2; return; }
         }
-#pragma unroll 4
-        for (uint32_t u = 0; u < DEC_PREP_B; u++) {
-            const uint32_t widx = widx0 + j + u;
-            if (!have || widx + 1 >= base + 64) {
-                v = stream_word64(bs, widx + lane);
-                base = widx;
-                have = 1;
-            }
-            const uint32_t k = widx - base;
-            const uint64_t lo = readlane64(v, k), hi = readlane64(v, k + 1);
-            const uint64_t bb = lane ? ((lo >> lane) | (hi << (64 - lane))) : lo;
-            uint32_t pl = (uint32_t)(bb >> 1) & 0xFFu, ns = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t s = pl & 1u;
-                pl >>= 1 + s;
-                ns += s;
-            }
-            const uint32_t slot = (j + u) % DEC_PREP;
-            sh.plav[slot][lane] = (uint8_t)((bb & 1u) ? 5 + ns : 0);  // non-zero <=> the stream bit is 1
-            if (lane < 2) sh.wbits[(j + u) % (DEC_PREP + DEC_RING)][lane] = lane ? hi : lo;
+        const uint64_t lo = nlo, hi = nhi;
+        nlo = stream_word64(bs, widx0 + j + DEC_PREP_B + uw);
+        nhi = stream_word64(bs, widx0 + j + DEC_PREP_B + uw + 1u);
+        // X(k): bit q = stream bit q + k of the window
+#define HX(k) ((lo >> (k)) | (hi << (64 - (k))))
+        const uint64_t s1 = HX(1);
+        const uint64_t s2 = (s1 & HX(3)) | (~s1 & HX(2));
+        const uint64_t a0 = s1 ^ s2, a1 = s1 & s2;                                       // s1 + s2
+        const uint64_t s3 = (a1 & HX(5)) | (~a1 & ((a0 & HX(4)) | (~a0 & HX(3))));
+        const uint64_t b0 = a0 ^ s3, b1 = a1 | (a0 & s3);                                // s1 + s2 + s3
+        const uint64_t s4 = (b1 & ((b0 & HX(7)) | (~b0 & HX(6)))) | (~b1 & ((b0 & HX(5)) | (~b0 & HX(4))));
+        const uint64_t cy = b0 & s4;
+        const uint64_t e0 = b0 ^ s4, e1 = b1 ^ cy, e2 = b1 & cy;                         // the four of them: 0 .. 4
+#undef HX
+        const uint32_t tslot = (j + uw) % DEC_PREP;
+        if (hf == 0) {
+            uint64_t *row = sh.pln[tslot];
+            row[0] = e0; row[1] = e1; row[2] = e2; row[3] = lo;
+            uint64_t *wb = sh.wbits[(j + uw) % (DEC_PREP + DEC_RING)];
+            wb[0] = lo; wb[1] = hi;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);
-        // Every second batch: the last 32 windows walked under the all-type-A hypothesis (DecShared::tabfm).  Lane = (window,
-        // half): each walks the window from entry point 0 in full -- a dozen steps at most, a fired entry takes five bits or
-        // more -- and then four of the other eight entry points (half 0: 1..4, half 1: 5..8) only until they fall in step
-        // with that walk, which they do after a token or two (the code synchronises itself).  Same token lengths as plav
-        // above: 5 + the significant ones among the four offspring that follow.  Behind the announcement of the batch: the
-        // sequencer never waits for a table, it hops through a window whose table is not there yet.
-        if ((j & DEC_PREP_B) != 0) {
-            static_assert(DEC_PREP_B == 16 && DEC_PREP % 32 == 0, "two batches = the 32 windows of a table pass");
-            const uint32_t tb = j - DEC_PREP_B, uw = lane & 31u, hf = lane >> 5;
-            const uint64_t *wb = sh.wbits[(tb + uw) % (DEC_PREP + DEC_RING)];
-            asm volatile("" ::: "memory");  // (this wavefront's LDS writes above are read back here: in order)
-            const uint64_t lo = wb[0], hi = wb[1];
-            const uint32_t tslot = (tb + uw) % DEC_PREP;
-            auto tok_len = [&](uint32_t q) -> uint32_t {  // length of the fired entry that starts at bit q
-                const uint64_t bq = q ? ((lo >> q) | (hi << (64u - q))) : lo;
-                uint32_t pl = (uint32_t)(bq >> 1) & 0xFFu, ns = 0;
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const uint32_t sg = pl & 1u;
-                    pl >>= 1 + sg;
-                    ns += sg;
-                }
-                return 5u + ns;
-            };
-            // entry point 0: S0 = every bit at which an entry starts, fm0 = the fired ones among them
-            uint64_t S0 = 0, fm0 = 0;
-            uint32_t p = 0;
-            while (p < 64u) {
-                const uint64_t rem = lo >> p;
-                if (rem == 0) { S0 |= ~0ull << p; p = 64u; break; }  // zeros to the end: one-bit entries
-                const uint32_t q = p + (uint32_t)__builtin_ctzll(rem);
-                S0 |= ((2ull << (q - p)) - 1ull) << p;  // the zeros p .. q-1 and the fired entry at q
-                fm0 |= 1ull << q;
-                p = q + tok_len(q);
-            }
-            const uint32_t exit0 = p - 64u;
-            if (hf == 0) {
-                sh.tabfm[tslot][0] = fm0;
-                sh.tabce[tslot][0] = (uint16_t)((uint32_t)__popcll(S0) | (exit0 << 7));
-            }
-            for (uint32_t o = 1u + 4u * hf; o < 5u + 4u * hf; o++) {
-                uint32_t pp = o, cnt = 0, ex = 0;
-                uint64_t fmk = 0;
-                for (;;) {
-                    if (pp >= 64u) { ex = pp - 64u; break; }  // never met the walk from 0
-                    // one-bit entries up to the next bit that is set or lies on the walk from 0
-                    const uint32_t z = (uint32_t)__builtin_ctzll(((lo | S0) >> pp) | (1ull << (63u - pp)));
-                    cnt += z;
-                    pp += z;
-                    if ((S0 >> pp) & 1ull) {  // in step from here on
-                        cnt += (uint32_t)__popcll(S0 >> pp);
-                        fmk |= fm0 & (~0ull << pp);
-                        ex = exit0;
-                        break;
-                    }
-                    if (!((lo >> pp) & 1ull)) { cnt += 1; ex = 0; pp = 64u; break; }  // (bit 63, a zero off the walk: the last entry)
-                    fmk |= 1ull << pp;
-                    cnt += 1;
-                    pp += tok_len(pp);
-                }
-                sh.tabfm[tslot][o] = fmk;
-                sh.tabce[tslot][o] = (uint16_t)(cnt | (ex << 7));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) lds_store(&sh.tprog, j + DEC_PREP_B);
+        if (lane == 0) lds_store(&sh.pprog, j + DEC_PREP_B);  // the sequencer can hop through these windows from here on
+        auto tok_len = [&](uint32_t q) -> uint32_t {  // length of the fired entry that starts at bit q
+            return 5u + ((uint32_t)(e0 >> q) & 1u) + 2u * ((uint32_t)(e1 >> q) & 1u) + 4u * ((uint32_t)(e2 >> q) & 1u);
+        };
+        // entry point 0: S0 = every bit at which an entry starts, fm0 = the fired ones among them
+        uint64_t S0 = 0, fm0 = 0;
+        uint32_t p = 0;
+        while (p < 64u) {
+            const uint64_t rem = lo >> p;
+            if (rem == 0) { S0 |= ~0ull << p; p = 64u; break; }  // zeros to the end: one-bit entries
+            const uint32_t q = p + (uint32_t)__builtin_ctzll(rem);
+            S0 |= ((2ull << (q - p)) - 1ull) << p;  // the zeros p .. q-1 and the fired entry at q
+            fm0 |= 1ull << q;
+            p = q + tok_len(q);
         }
+        const uint32_t exit0 = p - 64u;
+        if (hf == 0) {
+            sh.tabfm[tslot][0] = fm0;
+            sh.tabce[tslot][0] = (uint16_t)((uint32_t)__popcll(S0) | (exit0 << 7));
+        }
+        for (uint32_t o = 1u + 4u * hf; o < 5u + 4u * hf; o++) {
+            uint32_t pp = o, cnt = 0, ex = 0;
+            uint64_t fmk = 0;
+            for (;;) {
+                if (pp >= 64u) { ex = pp - 64u; break; }  // never met the walk from 0
+                // one-bit entries up to the next bit that is set or lies on the walk from 0
+                const uint32_t z = (uint32_t)__builtin_ctzll(((lo | S0) >> pp) | (1ull << (63u - pp)));
+                cnt += z;
+                pp += z;
+                if ((S0 >> pp) & 1ull) {  // in step from here on
+                    cnt += (uint32_t)__popcll(S0 >> pp);
+                    fmk |= fm0 & (~0ull << pp);
+                    ex = exit0;
+                    break;
+                }
+                if (!((lo >> pp) & 1ull)) { cnt += 1; ex = 0; pp = 64u; break; }  // (bit 63, a zero off the walk: the last entry)
+                fmk |= 1ull << pp;
+                cnt += 1;
+                pp += tok_len(pp);
+            }
+            sh.tabfm[tslot][o] = fmk;
+            sh.tabce[tslot][o] = (uint16_t)(cnt | (ex << 7));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_store(&sh.tprog, j + DEC_PREP_B);  // ... and look them up from here on
     }
 }
 
@@ -959,7 +948,7 @@ void k_decode(DecArgs a) {
         uint32_t myk = DEC_IS_WORKER(wave) ? DEC_WK(wave) : 0;  // worker: sequence number of its next item
         uint32_t phase = 0;
 #ifdef DEC_PROF
-        uint64_t pf[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t pf[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1149,7 +1138,6 @@ void k_decode(DecArgs a) {
                     const uint32_t widx0s = sP >> 6;  // first window of the phase (the helper starts there too)
                     uint32_t pknown = 0;              // windows known to be prepared
                     uint32_t tknown = 0;              // ... and to have their all-type-A table (DecShared::tabfm)
-                    bool prev_table = false;          // the window before was looked up in that table
                     uint32_t sFc = (0u - sSeq) & (DEC_RING / 2 - 1);  // publishes until the next ring-space check
                     const uint32_t cur_len_v = cur_len;
                     const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
@@ -1217,7 +1205,6 @@ void k_decode(DecArgs a) {
                             }
                         }
                         const uint32_t pslot = kw % DEC_PREP;
-                        const uint32_t LAv = sh.plav[pslot][lane];
                         const uint32_t vb = (sNb - Wb) < 64u ? (sNb - Wb) : 64u;
                         const uint32_t i0 = i;
                         uint64_t fm = 0;
@@ -1239,25 +1226,42 @@ void k_decode(DecArgs a) {
                             const uint64_t TAc = readlane64(TAv, ch - blk0), TAn = readlane64(TAv, ch + 1 - blk0);
                             uint64_t Tr = r0 ? ((TAc >> r0) | (TAn << (64u - r0))) : TAc;
                             asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
-                            // Every entry this window can meet is a type-A entry with offspring (64 of them: an entry takes a
-                            // bit at least), the window is whole and starts at most eight bits in (a token is nine bits at
-                            // most: true of every window but a phase's first): the helper has walked it for that entry point
-                            // already (DecShared::tabfm) -- one look-up instead of a hop per fired entry.  Four windows of
-                            // five on a 4096 x 4096 picture, one of two at 1080p (profiles/r04_lis_type_runs.txt).
-                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw >= tknown) tknown = RFL(lds_load(&sh.tprog));
-                            if (Tr == ~0ull && pos0 <= 8u && vb == 64u && kw < tknown) {
+                            // The window is whole and starts at most eight bits in (a token is nine bits at most: true of every
+                            // window but a phase's first): the helper has walked it for that entry point already under the
+                            // hypothesis "every entry is a type-A entry with offspring" (DecShared::tabfm).  That walk is THIS
+                            // window's walk if the entries it met -- `cnt` of them, 19 on average at 1080p, not the 64 a window
+                            // can reach at most -- are all of that type: one look-up instead of a hop per fired entry, for 72 %
+                            // of the windows with 84 % of the fired entries at 1080p (profiles/r04_lis_type_runs.txt).
+                            const bool tab_try = (Tr & 1ull) != 0 && pos0 <= 8u && vb == 64u;
+                            if (tab_try && kw >= tknown) tknown = RFL(lds_load(&sh.tprog));
+                            PF_CNT(18, tab_try ? 1 : 0);
+                            PF_CNT(19, tab_try && kw >= tknown ? 1 : 0);
+                            PF_CNT(21, (Tr & 1ull) ? 0 : 1);
+                            PF_CNT(22, (Tr & 1ull) != 0 && !(pos0 <= 8u && vb == 64u) ? 1 : 0);
+                            if (tab_try && kw < tknown) {
                                 const uint32_t tl = lane < 9u ? lane : 0u;
                                 const uint64_t tfm = sh.tabfm[pslot][tl];
                                 const uint32_t tce = sh.tabce[pslot][tl];
-                                fm = readlane64(tfm, pos0);
                                 const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)pos0);
-                                rel = ce & 0x7Fu;
-                                pos = 64u + (ce >> 7);
-                                i += rel;
-                                by_table = true;
-                                PF_CNT(5, 1);
-                            } else {
-                            const uint64_t lo = __ballot(LAv != 0);  // the window's bits (see DecShared::plav)
+                                const uint32_t cnt = ce & 0x7Fu;
+                                const uint32_t na = Tr == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~Tr);  // type-A entries ahead
+                                if (cnt <= na) {  // the table's walk met type-A entries only: it is this window's walk
+                                    fm = readlane64(tfm, pos0);
+                                    rel = cnt;
+                                    pos = 64u + (ce >> 7);
+                                    i += rel;
+                                    by_table = true;
+                                    PF_CNT(5, 1);
+                                } else PF_CNT(20, 1);
+                            }
+                            if (!by_table) {
+                            // the window's bits and, one per lane, the length a fired type-A entry would have at that position
+                            // (DecShared::pln: three bit planes of length - 5)
+                            const uint32_t *prow = reinterpret_cast<const uint32_t *>(sh.pln[pslot]) + (lane >> 5);  // the lane's half
+                            const uint32_t pe0 = prow[0], pe1 = prow[2], pe2 = prow[4], sl = lane & 31u;
+                            const uint64_t plo = sh.pln[pslot][3];
+                            const uint64_t lo = ((uint64_t)RFL((uint32_t)(plo >> 32)) << 32) | RFL((uint32_t)plo);
+                            const uint32_t LAv = 5u + ((pe0 >> sl) & 1u) + 2u * ((pe1 >> sl) & 1u) + 4u * ((pe2 >> sl) & 1u);
                             uint64_t Lr = lo >> pos, c64;
                             uint32_t f, dd, len;
                             // The walk, hand-scheduled: this serial chain bounds the whole decoder and hipcc's version of
@@ -1331,7 +1335,7 @@ void k_decode(DecArgs a) {
                         // token lengths, the helper's progress -- and inside a stretch of the queue that is all type A none of
                         // that is needed: the entries ahead of type A are counted once (`ones`, from the chunk masks in TAv),
                         // and while 64 or more remain, a window is its table row and its slot: about thirty instructions.
-                        if (by_table && prev_table) {
+                        if (by_table) {
                             uint32_t ones = 0;
                             {
                                 const uint32_t c2 = i >> 6, r2 = i & 63u;
@@ -1352,23 +1356,34 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                             const uint64_t trl = __builtin_amdgcn_s_memtime();
 #endif
-                            while (ones >= 64u && rWb + 64u <= sNb) {
-                                if (rkw >= tknown) {
+                            // The table row of a window is fetched while the window before it is published: which row does not
+                            // depend on the walk, only which of its nine entries is taken does.
+                            const uint32_t tl = lane < 9u ? lane : 0u;
+                            uint64_t tfm = sh.tabfm[rkw % DEC_PREP][tl];
+                            uint32_t tce = sh.tabce[rkw % DEC_PREP][tl];
+                            bool pre = rkw < tknown;  // (a row read before its table was announced is not used)
+                            asm volatile("" ::: "memory");
+                            while (rWb + 64u <= sNb) {
+                                if (!pre) {
                                     tknown = RFL(lds_load(&sh.tprog));
-                                    if (rkw >= tknown) { PF_CNT(15, 1); break; }  // (the helper is not there yet: the walk above waits for it and hops)
+                                    if (rkw >= tknown) { PF_CNT(15, 1); break; }  // (the helper is not there yet: the walk above hops)
+                                    tfm = sh.tabfm[rkw % DEC_PREP][tl];
+                                    tce = sh.tabce[rkw % DEC_PREP][tl];
                                 }
-                                const uint32_t rs = rkw % DEC_PREP, tl = lane < 9u ? lane : 0u;
-                                const uint64_t tfm = sh.tabfm[rs][tl];
-                                const uint32_t tce = sh.tabce[rs][tl];
-                                const uint64_t fm2 = readlane64(tfm, rp0);
                                 const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)rp0);
+                                const uint64_t fm2 = readlane64(tfm, rp0);
+                                const uint32_t cnt = ce & 0x7Fu;
+                                if (cnt > ones) break;  // the window reaches past the type-A stretch
+                                pre = rkw + 1u < tknown;
+                                tfm = sh.tabfm[(rkw + 1u) % DEC_PREP][tl];
+                                tce = sh.tabce[(rkw + 1u) % DEC_PREP][tl];
+                                asm volatile("" ::: "memory");
 #ifdef DEC_PROF
                                 seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw, &pf[16]);
 #else
                                 seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw);
 #endif
                                 asm volatile("s_add_i32 %0, %0, 1" : "+s"(sSeq) : : "scc");
-                                const uint32_t cnt = ce & 0x7Fu;
                                 i += cnt;
                                 ones -= cnt;
                                 rp0 = ce >> 7;
@@ -1382,7 +1397,6 @@ void k_decode(DecArgs a) {
 #endif
                             sP = rWb + rp0;
                         }
-                        prev_table = by_table;
                         // exit test, once per window: queue exhausted (i == sCur) or stream exhausted (sP >= sNb); one sign
                         // test (all quantities are below 2^31) instead of two compare / select pairs
                         if ((int32_t)((sCur - 1u - i) | (sNb - 1u - sP)) < 0) break;
@@ -1535,7 +1549,7 @@ void k_decode(DecArgs a) {
             if (ecode) atomicOr(a.err, ecode);
 #ifdef DEC_PROF
             PF_ADD(9);
-            if (b == 0) for (int q = 0; q < 18; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q == 17 ? pf[q] : (pf[q] >> 10));
+            if (b == 0) for (int q = 0; q < 24; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q >= 17 ? pf[q] : (pf[q] >> 10));
 #endif
         }
         __syncthreads();

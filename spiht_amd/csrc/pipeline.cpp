@@ -14,6 +14,10 @@
 // The reference codes one image per call on the CPU (spiht_wrapper.py:142-216); this replaces a loop over such calls.
 #include "../../include/spiht_hip.h"
 
+#ifndef PIPE_DEC_WAVES
+#define PIPE_DEC_WAVES 8  // the lighter neighbour for the HBM-bound kernels (decode.hip); -DPIPE_DEC_WAVES=12 for A/B runs
+#endif
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -132,7 +136,7 @@ static int pipeline_create(spiht_ctx *h_ctx, int device, int64_t B, int64_t c, i
     for (int s = 0; s < 2 && st == SPIHT_OK; s++) {
         if ((st = spiht_ctx_create(device, &p->Lc[s])) != SPIHT_OK) break;
         // decoder workgroups of 8 wavefronts: a longer walk, a lighter neighbour for the transforms beside it
-        if ((st = spiht_ctx_set_decoder_waves(p->Lc[s], 8)) != SPIHT_OK) break;
+        if ((st = spiht_ctx_set_decoder_waves(p->Lc[s], PIPE_DEC_WAVES)) != SPIHT_OK) break;
         // one workgroup per image whatever the batch size: the several-CUs-per-image encoder is for single calls -- its
         // workgroups take a whole CU each and would wait for the transforms beside them to leave one
         if ((st = spiht_ctx_set_option(p->Lc[s], "wide_encode", 0)) != SPIHT_OK) break;

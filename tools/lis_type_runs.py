@@ -88,6 +88,19 @@ def analyse(name, data, n, c, h, w, lh, lw):
           "holding %.1f %% of the fired type-A entries (the sequencer's hops: %d in all, %.2f per window)"
           % (fi.size, int(uniform.sum()), 100.0 * uniform.sum() / fi.size, 100.0 * hops_in_uniform / max(1, int(fa_ent.sum())),
              int(fa_ent.sum()), fa_ent.sum() / fi.size))
+    # the same windows by the types of the entries that actually START in them (a window with fired entries reaches far fewer
+    # than 64 entries): kinds A, B, AB (type A then type B), BA, and more changes than one
+    chg = (ent_type[1:] != ent_type[:-1]).astype(np.int64)
+    cchg = np.concatenate([[0], np.cumsum(chg)])               # changes before entry i (between i-1 and i counted at i)
+    last = nxt_fi - 1
+    nchg = cchg[last] - cchg[fi]
+    first_t = ent_type[fi]
+    kinds = {"all A": (nchg == 0) & (first_t == 2), "all B": (nchg == 0) & (first_t == 5), "A then B": (nchg == 1) & (first_t == 2),
+             "B then A": (nchg == 1) & (first_t == 5), "two changes": nchg == 2, "three and more": nchg >= 3}
+    for k, m in kinds.items():
+        print("   windows whose own entries are %-15s %6d (%5.1f %%), %5.1f %% of the hops, %5.1f entries a window"
+              % (k + ":", int(m.sum()), 100.0 * m.sum() / fi.size, 100.0 * hops_per_win[m].sum() / max(1, int(fa_ent.sum())),
+                 (nxt_fi - fi)[m].mean() if m.any() else 0.0))
     return dict(bits=nb, entries=tot, hops=int(fa_ent.sum()), windows=int(fi.size), uniform_windows=int(uniform.sum()))
 
 

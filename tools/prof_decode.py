@@ -64,12 +64,12 @@ print("decoder kernel (HIP events): %.2f ms for %d images" % (ctx.timing()["deco
 words = (C.c_uint32 * 64)()
 L.spiht_debug_words.argtypes = [vp, vp]
 _lib.check(L.spiht_debug_words(ctx.handle, words))
-w = list(words)[16:34]
+w = list(words)[16:40]
 names = ["lip_seq", "lis_blocks", "lis_seq", "lis_wait", "refine", "table_windows", "items_lis", "other", "generations", "scatter", "blocks", "lis_publish", "lis_window", "lis_hops",
-         "run_loop", "run_breaks_table_late", "ring_wait", "run_windows"]
+         "run_loop", "run_breaks_table_late", "ring_wait", "run_windows", "table_tried", "table_late", "table_past_type_A", "first_entry_not_A", "window_not_whole", "-"]
 tot = sum(w[k] for k in (0, 1, 2, 3, 4, 7, 9))
 for k, nm in enumerate(names):
-    if k in (5, 6, 8, 10, 15, 17):
+    if k in (5, 6, 8, 10, 15) or k >= 17:
         print("%-12s %d" % (nm, w[k]))
     else:
         print("%-12s %8.3f Mcycles (%.1f%%)" % (nm, w[k] * 1024 / 1e6, 100.0 * w[k] / max(tot, 1)))
