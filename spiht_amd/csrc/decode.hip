@@ -113,6 +113,14 @@ struct LipItem {  // one LIP-pass window, produced by the parallel window scan
     uint32_t flags;  // pos0 | cin << 8 | hibit0 << 9 | valid << 10
 };
 
+// one window walked under the all-type-A hypothesis, per entry point 0..8 (see DecShared::tab)
+struct TabRow {
+    uint64_t fm[9];    // start positions of the fired entries ... as a mask over the entries that start in the window
+    uint16_t ce[9];    // entries that start in the window | (bits the last one hangs over into the next window) << 7
+    uint16_t pad[3];
+};
+static_assert(sizeof(TabRow) == 96, "the run loop of the sequencer steps through the rows in assembly");
+
 struct DecShared {
     // The LIP pass and the LIS pass never run at the same time (barriers between them), so their scratch shares
     // memory (the LIP scratch, 32 B per window of a round, is the larger of the two: 24.6 KB at 12 wavefronts).  The
@@ -127,7 +135,7 @@ struct DecShared {
             PhaseInfo ph;
             // helper -> sequencer: per window, the length a fired type-A entry would have at each of its 64 positions, as
             // three bit planes of (length - 5) and, fourth word, the window's bits themselves; the sequencer turns a row
-            // into one length per lane when it has to hop through the window (most windows it looks up, see tabfm)
+            // into one length per lane when it has to hop through the window (most windows it looks up, see tab)
             uint64_t pln[DEC_PREP][4];
             // helper -> workers: the bits of each window and of the one after it (zero at and past the end of the
             // stream), so that a worker's window costs it no stream load.  A worker can lag DEC_RING windows behind the
@@ -136,17 +144,16 @@ struct DecShared {
             // helper -> sequencer: the walk of each window under the hypothesis "every list entry this window meets is a
             // type-A entry with offspring" -- then which bits are entries depends on the bits alone: an entry is '0' or
             // '1' + 4..8 offspring bits, whatever its index in the queue.  Per entry point o = 0..8 (the window's first
-            // o bits belong to the previous window's last entry): tabfm = start positions of the fired entries, tabce =
+            // o bits belong to the previous window's last entry): TabRow::fm = start positions of the fired entries, ce =
             // entries that start in the window | (bits the last one hangs over into the next window) << 7.
-            uint64_t tabfm[DEC_PREP][9];
-            uint16_t tabce[DEC_PREP][9];
+            TabRow tab[DEC_PREP];
         };
     };
     uint64_t wpart[DEC_NW];     // per-wave partials of the block scans
     uint32_t wfun[DEC_NW];      // per-wave carry functions
     uint32_t lp_end[4];         // LIP pass end: [0] kind (0 none, 1 ends, 2 trunc), [1] P after the pass
     uint32_t pprog;             // windows of this phase the helper has prepared
-    uint32_t tprog;             // ... and walked under the all-type-A hypothesis (DecShared::tabfm): announced a little later
+    uint32_t tprog;             // ... and walked under the all-type-A hypothesis (DecShared::tab): announced a little later
     uint32_t sprog;             // windows of this phase the sequencer is done with (announced every DEC_RING/2 windows)
     uint32_t head;              // items produced so far
     uint32_t phase_end[2];      // sequence number at which the phase of that parity ends, SEQ_OPEN while open
@@ -344,33 +351,35 @@ __device__ __forceinline__ uint64_t block_exscan(DecShared &sh, uint64_t v, uint
 // LDS instructions of one wavefront execute in issue order, so the item words followed by the slot's `ready`
 // word need no wait in between; a worker that sees ready == k+1 sees item k.  Ring space is checked once per
 // half ring: before item k (k a multiple of RING/2) every item below k - RING/2 must have been consumed.
+__device__ __forceinline__ void seq_ring_check(DecShared &sh, uint32_t seq, uint32_t &fc, uint32_t lane, uint32_t kw, uint64_t *pfw) {
+    constexpr uint32_t HALF = DEC_RING / 2;
+    fc = HALF;
+    // the helper's ring entries of the windows before this one are free (announced here, every HALF windows,
+    // rather than with a test of its own per window)
+    if (lane == 0) __hip_atomic_store(&sh.sprog, kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (seq >= DEC_RING) {
+        const uint32_t lim = seq - HALF;  // items [0, lim) must be done
+        // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
+        const uint32_t w = lane < DEC_NWK ? lane : 0u;
+        const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
+        uint32_t spins = 0;
+#ifdef DEC_PROF
+        const uint64_t tws = __builtin_amdgcn_s_memtime();
+#endif
+        while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
+        }
+#ifdef DEC_PROF
+        if (pfw) *pfw += __builtin_amdgcn_s_memtime() - tws;
+#endif
+    }
+}
+
 __device__ __forceinline__ void seq_publish(DecShared &sh, uint32_t seq, uint32_t &fc, uint64_t fm, uint32_t e_start,
                                             uint32_t pos0, uint32_t pos1, uint32_t lane, uint32_t kw, uint64_t *pfw = nullptr) {
-    constexpr uint32_t HALF = DEC_RING / 2;
     // `seq` is wave-uniform (the caller keeps it in an SGPR); fc counts down to the next multiple of HALF
-    if (fc == 0) {
-        fc = HALF;
-        // the helper's ring entries of the windows before this one are free (announced here, every HALF windows,
-        // rather than with a test of its own per window)
-        if (lane == 0) __hip_atomic_store(&sh.sprog, kw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (seq >= DEC_RING) {
-            const uint32_t lim = seq - HALF;  // items [0, lim) must be done
-            // worker w takes items w, w + NWK, ...: lane w checks that worker's counter, one LDS read for all of them
-            const uint32_t w = lane < DEC_NWK ? lane : 0u;
-            const uint32_t need = lim > w ? (lim - w + DEC_NWK - 1) / DEC_NWK : 0;
-            uint32_t spins = 0;
-#ifdef DEC_PROF
-            const uint64_t tws = __builtin_amdgcn_s_memtime();
-#endif
-            while (__ballot(lds_load(&sh.wdone[w]) < need) != 0) {
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }  // never expected: keeps a bug from hanging the GPU
-            }
-#ifdef DEC_PROF
-            if (pfw) *pfw += __builtin_amdgcn_s_memtime() - tws;
-#endif
-        }
-    }
+    if (fc == 0) seq_ring_check(sh, seq, fc, lane, kw, pfw);
     asm volatile("s_add_i32 %0, %0, -1" : "+s"(fc) : : "scc");  // (asm: keeps the counter in an SGPR)
     if (lane == 0) {
         Slot *slot = &sh.ring[seq % DEC_RING];
@@ -795,7 +804,7 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
 // with bitwise operations on 64-bit words (the k-th offspring's bit is one of the window shifted by k .. 2k-1, chosen by the
 // two-bit count of significant ones before it), which leaves (length - 5) as three bit planes: some 80 instructions for 32
 // windows where one lane per position took 40 per window (round 4: the helper, not the sequencer, set the decoder's pace in
-// long stretches of looked-up windows).  Then the window walked under the all-type-A hypothesis (DecShared::tabfm): from
+// long stretches of looked-up windows).  Then the window walked under the all-type-A hypothesis (DecShared::tab): from
 // entry point 0 in full -- a dozen steps at most, a fired entry takes five bits or more -- and four of the other eight entry
 // points (half 0: 1..4, half 1: 5..8) only until they fall in step with that walk, which they do after a token or two (the
 // code synchronises itself).  The windows are announced before their table (DecShared::pprog, tprog): the sequencer never waits
@@ -852,8 +861,8 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
         }
         const uint32_t exit0 = p - 64u;
         if (hf == 0) {
-            sh.tabfm[tslot][0] = fm0;
-            sh.tabce[tslot][0] = (uint16_t)((uint32_t)__popcll(S0) | (exit0 << 7));
+            sh.tab[tslot].fm[0] = fm0;
+            sh.tab[tslot].ce[0] = (uint16_t)((uint32_t)__popcll(S0) | (exit0 << 7));
         }
         for (uint32_t o = 1u + 4u * hf; o < 5u + 4u * hf; o++) {
             uint32_t pp = o, cnt = 0, ex = 0;
@@ -875,8 +884,8 @@ __device__ __forceinline__ void helper_phase(DecShared &sh, const BitSrc &bs, ui
                 cnt += 1;
                 pp += tok_len(pp);
             }
-            sh.tabfm[tslot][o] = fmk;
-            sh.tabce[tslot][o] = (uint16_t)(cnt | (ex << 7));
+            sh.tab[tslot].fm[o] = fmk;
+            sh.tab[tslot].ce[o] = (uint16_t)(cnt | (ex << 7));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.tprog, j + DEC_PREP_B);  // ... and look them up from here on
@@ -1137,7 +1146,7 @@ void k_decode(DecArgs a) {
                     uint32_t sP = RFL(P), sSeq = RFL(seq);
                     const uint32_t widx0s = sP >> 6;  // first window of the phase (the helper starts there too)
                     uint32_t pknown = 0;              // windows known to be prepared
-                    uint32_t tknown = 0;              // ... and to have their all-type-A table (DecShared::tabfm)
+                    uint32_t tknown = 0;              // ... and to have their all-type-A table (DecShared::tab)
                     uint32_t sFc = (0u - sSeq) & (DEC_RING / 2 - 1);  // publishes until the next ring-space check
                     const uint32_t cur_len_v = cur_len;
                     const uint32_t sCur = RFL(cur_len_v), sNb = RFL(nbits);
@@ -1228,7 +1237,7 @@ void k_decode(DecArgs a) {
                             asm volatile("" ::: "memory");  // keep the LDS reads issued above, their first use below
                             // The window is whole and starts at most eight bits in (a token is nine bits at most: true of every
                             // window but a phase's first): the helper has walked it for that entry point already under the
-                            // hypothesis "every entry is a type-A entry with offspring" (DecShared::tabfm).  That walk is THIS
+                            // hypothesis "every entry is a type-A entry with offspring" (DecShared::tab).  That walk is THIS
                             // window's walk if the entries it met -- `cnt` of them, 19 on average at 1080p, not the 64 a window
                             // can reach at most -- are all of that type: one look-up instead of a hop per fired entry, for 72 %
                             // of the windows with 84 % of the fired entries at 1080p (profiles/r04_lis_type_runs.txt).
@@ -1240,8 +1249,8 @@ void k_decode(DecArgs a) {
                             PF_CNT(22, (Tr & 1ull) != 0 && !(pos0 <= 8u && vb == 64u) ? 1 : 0);
                             if (tab_try && kw < tknown) {
                                 const uint32_t tl = lane < 9u ? lane : 0u;
-                                const uint64_t tfm = sh.tabfm[pslot][tl];
-                                const uint32_t tce = sh.tabce[pslot][tl];
+                                const uint64_t tfm = sh.tab[pslot].fm[tl];
+                                const uint32_t tce = sh.tab[pslot].ce[tl];
                                 const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)pos0);
                                 const uint32_t cnt = ce & 0x7Fu;
                                 const uint32_t na = Tr == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~Tr);  // type-A entries ahead
@@ -1356,41 +1365,95 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
                             const uint64_t trl = __builtin_amdgcn_s_memtime();
 #endif
-                            // The table row of a window is fetched while the window before it is published: which row does not
-                            // depend on the walk, only which of its nine entries is taken does.
+                            // The loop itself is written out (the compiler's version of it is 55 instructions with nine
+                            // branches, and the sequencer retires an instruction per ten cycles whatever it is): per window
+                            // the row of the table is read a window ahead -- which row does not depend on the walk, only which
+                            // of its nine entries is taken --, the entry's count is held against the type-A entries left, the
+                            // slot is written by lane 0 (three LDS writes, the flag last: one wavefront's LDS writes stay in
+                            // order) and the walk's four numbers move on: 36 instructions, one branch.  It runs for as many
+                            // windows as need no look at anything else: up to the next ring-space check, the tables known
+                            // to be there, the whole windows left of the stream.
+                            static_assert(DEC_PREP == 64 && DEC_RING == 64 && sizeof(Slot) == 32, "constants of the loop below");
                             const uint32_t tl = lane < 9u ? lane : 0u;
-                            uint64_t tfm = sh.tabfm[rkw % DEC_PREP][tl];
-                            uint32_t tce = sh.tabce[rkw % DEC_PREP][tl];
-                            bool pre = rkw < tknown;  // (a row read before its table was announced is not used)
-                            asm volatile("" ::: "memory");
-                            while (rWb + 64u <= sNb) {
-                                if (!pre) {
+                            const uint32_t a_tab = (uint32_t)(uintptr_t)&sh.tab[0], a_ring = (uint32_t)(uintptr_t)&sh.ring[0];
+                            const uint32_t vbfm = a_tab + tl * 8u, vbce = a_tab + 72u + tl * 2u;
+                            for (;;) {
+                                if (rWb + 64u > sNb) break;
+                                if (rkw >= tknown) {
                                     tknown = RFL(lds_load(&sh.tprog));
                                     if (rkw >= tknown) { PF_CNT(15, 1); break; }  // (the helper is not there yet: the walk above hops)
-                                    tfm = sh.tabfm[rkw % DEC_PREP][tl];
-                                    tce = sh.tabce[rkw % DEC_PREP][tl];
                                 }
-                                const uint32_t ce = (uint32_t)__builtin_amdgcn_readlane((int)tce, (int)rp0);
-                                const uint64_t fm2 = readlane64(tfm, rp0);
-                                const uint32_t cnt = ce & 0x7Fu;
-                                if (cnt > ones) break;  // the window reaches past the type-A stretch
-                                pre = rkw + 1u < tknown;
-                                tfm = sh.tabfm[(rkw + 1u) % DEC_PREP][tl];
-                                tce = sh.tabce[(rkw + 1u) % DEC_PREP][tl];
-                                asm volatile("" ::: "memory");
 #ifdef DEC_PROF
-                                seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw, &pf[16]);
+                                if (sFc == 0) seq_ring_check(sh, sSeq, sFc, lane, rkw, &pf[16]);
 #else
-                                seq_publish(sh, sSeq, sFc, fm2, i, rp0, 64u, lane, rkw);
+                                if (sFc == 0) seq_ring_check(sh, sSeq, sFc, lane, rkw, nullptr);
 #endif
-                                asm volatile("s_add_i32 %0, %0, 1" : "+s"(sSeq) : : "scc");
-                                i += cnt;
-                                ones -= cnt;
-                                rp0 = ce >> 7;
-                                rkw += 1u;
-                                rWb += 64u;
-                                PF_CNT(5, 1);
-                                PF_CNT(17, 1);
+                                uint32_t n = sFc;
+                                n = n < tknown - rkw ? n : tknown - rkw;
+                                n = n < ((sNb - rWb) >> 6) ? n : ((sNb - rWb) >> 6);
+                                const uint32_t n0 = n;
+                                uint32_t row = RFL((rkw % DEC_PREP) * (uint32_t)sizeof(TabRow));
+                                n = RFL(n); rp0 = RFL(rp0); i = RFL(i); ones = RFL(ones);  // (wave-uniform all: tells the compiler so)
+                                uint32_t va1, va2, vlo, vhi, vce, vs, d0, d1, d2, d3, d4, ce, f0, f1, cnt, t;
+                                asm volatile(
+                                    "v_add_u32 %[va1], %[row], %[vbfm]\n\t"
+                                    "v_add_u32 %[va2], %[row], %[vbce]\n\t"
+                                    "ds_read_b32 %[vlo], %[va1]\n\t"
+                                    "ds_read_b32 %[vhi], %[va1] offset:4\n\t"
+                                    "ds_read_u16 %[vce], %[va2]\n\t"
+                                    "s_waitcnt lgkmcnt(0)\n"
+                                    "s_runl%=:\n\t"
+                                    "v_readlane_b32 %[ce], %[vce], %[rp0]\n\t"
+                                    "v_readlane_b32 %[f0], %[vlo], %[rp0]\n\t"
+                                    "v_readlane_b32 %[f1], %[vhi], %[rp0]\n\t"
+                                    "s_add_u32 %[row], %[row], 96\n\t"
+                                    "s_cmp_eq_u32 %[row], 6144\n\t"
+                                    "s_cselect_b32 %[row], 0, %[row]\n\t"
+                                    "v_add_u32 %[va1], %[row], %[vbfm]\n\t"
+                                    "v_add_u32 %[va2], %[row], %[vbce]\n\t"
+                                    "s_and_b32 %[cnt], %[ce], 0x7f\n\t"
+                                    "ds_read_b32 %[vlo], %[va1]\n\t"
+                                    "ds_read_b32 %[vhi], %[va1] offset:4\n\t"
+                                    "ds_read_u16 %[vce], %[va2]\n\t"
+                                    "s_cmp_gt_u32 %[cnt], %[ones]\n\t"
+                                    "s_cbranch_scc1 s_rund%=\n\t"
+                                    "s_mov_b64 exec, 1\n\t"
+                                    "s_and_b32 %[t], %[seq], 63\n\t"
+                                    "s_lshl_b32 %[t], %[t], 5\n\t"
+                                    "v_add_u32 %[vs], %[t], %[vring]\n\t"
+                                    "v_mov_b32 %[d0], %[f0]\n\t"
+                                    "v_mov_b32 %[d1], %[f1]\n\t"
+                                    "v_mov_b32 %[d2], %[i]\n\t"
+                                    "s_or_b32 %[t], %[rp0], 0x4000\n\t"
+                                    "v_mov_b32 %[d3], %[t]\n\t"
+                                    "ds_write2_b32 %[vs], %[d0], %[d1] offset1:1\n\t"
+                                    "ds_write2_b32 %[vs], %[d2], %[d3] offset0:2 offset1:3\n\t"
+                                    "s_add_u32 %[seq], %[seq], 1\n\t"
+                                    "v_mov_b32 %[d4], %[seq]\n\t"
+                                    "ds_write_b32 %[vs], %[d4] offset:16\n\t"
+                                    "s_mov_b64 exec, -1\n\t"
+                                    "s_lshr_b32 %[rp0], %[ce], 7\n\t"
+                                    "s_add_u32 %[i], %[i], %[cnt]\n\t"
+                                    "s_sub_u32 %[ones], %[ones], %[cnt]\n\t"
+                                    "s_sub_u32 %[n], %[n], 1\n\t"
+                                    "s_cmp_lg_u32 %[n], 0\n\t"
+                                    "s_waitcnt lgkmcnt(3)\n\t"
+                                    "s_cbranch_scc1 s_runl%=\n"
+                                    "s_rund%=:\n\t"
+                                    "s_waitcnt lgkmcnt(0)\n\t"
+                                    : [rp0] "+s"(rp0), [i] "+s"(i), [ones] "+s"(ones), [seq] "+s"(sSeq), [n] "+s"(n), [row] "+s"(row),
+                                      [va1] "=&v"(va1), [va2] "=&v"(va2), [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [vce] "=&v"(vce),
+                                      [vs] "=&v"(vs), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4),
+                                      [ce] "=&s"(ce), [f0] "=&s"(f0), [f1] "=&s"(f1), [cnt] "=&s"(cnt), [t] "=&s"(t)
+                                    : [vbfm] "v"(vbfm), [vbce] "v"(vbce), [vring] "v"(a_ring)
+                                    : "scc", "memory");
+                                const uint32_t took = n0 - n;
+                                sFc -= took;
+                                rkw += took;
+                                rWb += 64u * took;
+                                PF_CNT(5, took);
+                                PF_CNT(17, took);
+                                if (n != 0) break;  // the next window reaches past the type-A stretch: the walk above takes it
                             }
 #ifdef DEC_PROF
                             pf[14] += __builtin_amdgcn_s_memtime() - trl;
