@@ -909,13 +909,17 @@ template <bool META>
 #define DEC_WAVES_PER_EU 5  // caps the kernel at 96 VGPRs (35 spilled, none on the sequencer's path: same speed alone,
 #endif                      // 6.95 ms) so that three DWT wavefronts per SIMD fit beside a resident decoder workgroup when
                             // the two run on different streams (bench.py --pipeline 1: 19.6 instead of 22.5 ms per step)
+#ifdef DEC_NUM_VGPR  // A/B builds: an exact register budget between the two occupancy steps
+__global__ __launch_bounds__(DEC_NW * 64) __attribute__((amdgpu_waves_per_eu(4, 5), amdgpu_num_vgpr(DEC_NUM_VGPR)))
+#else
 __global__ __launch_bounds__(DEC_NW * 64) __attribute__((amdgpu_waves_per_eu(DEC_WAVES_PER_EU, DEC_WAVES_PER_EU)))
+#endif
 void k_decode(DecArgs a) {
     __shared__ DecShared sh;
     constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
     const Geom g = a.g;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (uniform: the roles below are scalar branches, what derives from it stays in SGPRs)
     const uint32_t slot = blockIdx.x;
     const uint32_t W = (uint32_t)g.w;
 
@@ -1370,7 +1374,7 @@ void k_decode(DecArgs a) {
                             // the row of the table is read a window ahead -- which row does not depend on the walk, only which
                             // of its nine entries is taken --, the entry's count is held against the type-A entries left, the
                             // slot is written by lane 0 (three LDS writes, the flag last: one wavefront's LDS writes stay in
-                            // order) and the walk's four numbers move on: 36 instructions, one branch.  It runs for as many
+                            // order) and the walk's four numbers move on: 36 instructions, one branch, eight vector registers.  It runs for as many
                             // windows as need no look at anything else: up to the next ring-space check, the tables known
                             // to be there, the whole windows left of the stream.
                             static_assert(DEC_PREP == 64 && DEC_RING == 64 && sizeof(Slot) == 32, "constants of the loop below");
@@ -1394,7 +1398,7 @@ void k_decode(DecArgs a) {
                                 const uint32_t n0 = n;
                                 uint32_t row = RFL((rkw % DEC_PREP) * (uint32_t)sizeof(TabRow));
                                 n = RFL(n); rp0 = RFL(rp0); i = RFL(i); ones = RFL(ones);  // (wave-uniform all: tells the compiler so)
-                                uint32_t va1, va2, vlo, vhi, vce, vs, d0, d1, d2, d3, d4, ce, f0, f1, cnt, t;
+                                uint32_t va1, va2, vlo, vhi, vce, vs, d0, d1, ce, f0, f1, cnt;
                                 asm volatile(
                                     "v_add_u32 %[va1], %[row], %[vbfm]\n\t"
                                     "v_add_u32 %[va2], %[row], %[vbce]\n\t"
@@ -1418,21 +1422,21 @@ void k_decode(DecArgs a) {
                                     "s_cmp_gt_u32 %[cnt], %[ones]\n\t"
                                     "s_cbranch_scc1 s_rund%=\n\t"
                                     "s_mov_b64 exec, 1\n\t"
-                                    "s_and_b32 %[t], %[seq], 63\n\t"
-                                    "s_lshl_b32 %[t], %[t], 5\n\t"
-                                    "v_add_u32 %[vs], %[t], %[vring]\n\t"
                                     "v_mov_b32 %[d0], %[f0]\n\t"
                                     "v_mov_b32 %[d1], %[f1]\n\t"
-                                    "v_mov_b32 %[d2], %[i]\n\t"
-                                    "s_or_b32 %[t], %[rp0], 0x4000\n\t"
-                                    "v_mov_b32 %[d3], %[t]\n\t"
+                                    "s_and_b32 %[f0], %[seq], 63\n\t"
+                                    "s_lshl_b32 %[f0], %[f0], 5\n\t"
+                                    "v_add_u32 %[vs], %[f0], %[vring]\n\t"
+                                    "s_or_b32 %[f1], %[rp0], 0x4000\n\t"
                                     "ds_write2_b32 %[vs], %[d0], %[d1] offset1:1\n\t"
-                                    "ds_write2_b32 %[vs], %[d2], %[d3] offset0:2 offset1:3\n\t"
+                                    "v_mov_b32 %[d0], %[i]\n\t"
+                                    "v_mov_b32 %[d1], %[f1]\n\t"
                                     "s_add_u32 %[seq], %[seq], 1\n\t"
-                                    "v_mov_b32 %[d4], %[seq]\n\t"
-                                    "ds_write_b32 %[vs], %[d4] offset:16\n\t"
-                                    "s_mov_b64 exec, -1\n\t"
+                                    "ds_write2_b32 %[vs], %[d0], %[d1] offset0:2 offset1:3\n\t"
+                                    "v_mov_b32 %[d0], %[seq]\n\t"
                                     "s_lshr_b32 %[rp0], %[ce], 7\n\t"
+                                    "ds_write_b32 %[vs], %[d0] offset:16\n\t"
+                                    "s_mov_b64 exec, -1\n\t"
                                     "s_add_u32 %[i], %[i], %[cnt]\n\t"
                                     "s_sub_u32 %[ones], %[ones], %[cnt]\n\t"
                                     "s_sub_u32 %[n], %[n], 1\n\t"
@@ -1443,8 +1447,8 @@ void k_decode(DecArgs a) {
                                     "s_waitcnt lgkmcnt(0)\n\t"
                                     : [rp0] "+s"(rp0), [i] "+s"(i), [ones] "+s"(ones), [seq] "+s"(sSeq), [n] "+s"(n), [row] "+s"(row),
                                       [va1] "=&v"(va1), [va2] "=&v"(va2), [vlo] "=&v"(vlo), [vhi] "=&v"(vhi), [vce] "=&v"(vce),
-                                      [vs] "=&v"(vs), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3), [d4] "=&v"(d4),
-                                      [ce] "=&s"(ce), [f0] "=&s"(f0), [f1] "=&s"(f1), [cnt] "=&s"(cnt), [t] "=&s"(t)
+                                      [vs] "=&v"(vs), [d0] "=&v"(d0), [d1] "=&v"(d1),
+                                      [ce] "=&s"(ce), [f0] "=&s"(f0), [f1] "=&s"(f1), [cnt] "=&s"(cnt)
                                     : [vbfm] "v"(vbfm), [vbce] "v"(vbce), [vring] "v"(a_ring)
                                     : "scc", "memory");
                                 const uint32_t took = n0 - n;
