@@ -411,9 +411,9 @@ extern "C" int spiht_ctx_create_priority(int device, int priority, spiht_ctx **o
         ctx->log2_thresh[k] = t;
     }
     for (int s = 0; s < ST_COUNT; s++) { ctx->ms[s] = 0; ctx->launches[s] = 0; }
-    int rc = ensure(ctx, ctx->err, 256);
+    int rc = ensure(ctx, ctx->err, 8192);  // (one error word; the rest is for diagnostic builds)
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
-    (void)hipMemset(ctx->err.p, 0, 256);
+    (void)hipMemset(ctx->err.p, 0, 8192);
     rc = ensure(ctx, ctx->tilebuf, TILECTR_WORDS * sizeof(uint32_t));
     if (rc != SPIHT_OK) { spiht_ctx_destroy(ctx); return rc; }
     (void)hipMemset(ctx->tilebuf.p, 0, TILECTR_WORDS * sizeof(uint32_t));
@@ -2104,6 +2104,13 @@ extern "C" int spiht_debug_words(spiht_ctx *ctx, uint32_t *out64) {
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HIPCHK(hipMemcpy(out64, ctx->err.p, 256, hipMemcpyDeviceToHost));
+    return SPIHT_OK;
+}
+extern "C" int spiht_debug_words_ext(spiht_ctx *ctx, uint32_t *out2048) {
+    if (!ctx || !out2048) return SPIHT_ERR_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(out2048, ctx->err.p, 8192, hipMemcpyDeviceToHost));
     return SPIHT_OK;
 }
 #endif  // SPIHT_DIAG

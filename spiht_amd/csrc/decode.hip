@@ -770,6 +770,11 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
                                              uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
                                              int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr,
                                              const BitSrc &bs) {
+    // The window's queue entries are its one trip to memory, and beside an HBM-bound kernel that trip is what a window
+    // costs (round 4: the sequencer waited for ring space a fifth of its time there): the entries of this worker's NEXT
+    // window are requested, if the sequencer has published it already, before the current one is worked on.
+    bool have_next = false;
+    uint32_t pre_next = 0;
     for (;;) {
         bool got = false;
         uint32_t spins = 0;
@@ -788,8 +793,22 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
         }
         if (!got) break;
         // the window's queue entries first (the only trip to memory of the window), then its bits from LDS
-        const uint32_t e0 = sh.ring[myk % DEC_RING].e_start + lane;
-        const uint32_t pre = cur[e0 < cur_len ? e0 : cur_len - 1u];
+        uint32_t pre;
+        if (have_next) pre = pre_next;
+        else {
+            const uint32_t e0 = sh.ring[myk % DEC_RING].e_start + lane;
+            pre = cur[e0 < cur_len ? e0 : cur_len - 1u];
+        }
+        {
+            const uint32_t kn = myk + DEC_NWK;
+            Slot *sn = &sh.ring[kn % DEC_RING];
+            have_next = __hip_atomic_load(&sn->ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == kn + 1;
+            asm volatile("" ::: "memory");
+            if (have_next) {
+                const uint32_t e1 = sn->e_start + lane;
+                pre_next = cur[e1 < cur_len ? e1 : cur_len - 1u];
+            }
+        }
         const Item it = slot_unpack(sh, bs, myk);
         work_lis<META>(sh, a, g, it, myk, pre, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -963,6 +982,7 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
         uint64_t pf[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         uint64_t pt = __builtin_amdgcn_s_memtime();
+        const uint64_t pf_rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock does
 #endif
 
         __syncthreads();  // previous image fully finished with the shared state
@@ -1617,6 +1637,13 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
             PF_ADD(9);
             if (b == 0) for (int q = 0; q < 24; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q >= 17 ? pf[q] : (pf[q] >> 10));
+            if (b < 448) {  // where and when this workgroup ran (tools/prof_decode.py: spread over the CUs, stragglers)
+                uint32_t *r = a.err + 64 + 4 * b;
+                r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
+                r[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+                r[2] = (uint32_t)pf_rt0;
+                r[3] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            }
 #endif
         }
         __syncthreads();

@@ -74,3 +74,20 @@ for k, nm in enumerate(names):
     else:
         print("%-12s %8.3f Mcycles (%.1f%%)" % (nm, w[k] * 1024 / 1e6, 100.0 * w[k] / max(tot, 1)))
 print("total %.3f Mcycles of the sequencer wavefront (s_memtime: shader clocks, 2.1-2.4 GHz => about %.2f ms)" % (tot * 1024 / 1e6, tot * 1024 / 2.4e9 * 1e3))
+
+if B > 1:
+    ext = (C.c_uint32 * 2048)()
+    L.spiht_debug_words_ext.argtypes = [vp, vp]
+    _lib.check(L.spiht_debug_words_ext(ctx.handle, ext))
+    r = np.array(list(ext)[64:64 + 4 * min(B, 448)], dtype=np.int64).reshape(-1, 4)
+    cu = (r[:, 1] & 15) * 64 + ((r[:, 0] >> 13) & 7) * 16 + ((r[:, 0] >> 12) & 1) * 8 + ((r[:, 0] >> 8) & 15)   # (xcc, se, sh, cu): an id, not a count
+    t0 = (r[:, 2] - r[:, 2].min()) % (1 << 32)
+    dur = (r[:, 3] - r[:, 2]) % (1 << 32)
+    ids, cnt = np.unique(cu, return_counts=True)
+    print("workgroups: %d on %d different CUs (%d CUs with 2, %d with 3 and more)" % (len(cu), len(ids), int((cnt == 2).sum()), int((cnt >= 3).sum())))
+    print("start after the first [us]: median %.1f, 90 %% %.1f, max %.1f" % (np.median(t0) / 100, np.percentile(t0, 90) / 100, t0.max() / 100))
+    print("duration [ms]: min %.2f, median %.2f, 90 %% %.2f, max %.2f; end of the last after the first start %.2f" %
+          (dur.min() / 1e5, np.median(dur) / 1e5, np.percentile(dur, 90) / 1e5, dur.max() / 1e5, (t0 + dur).max() / 1e5))
+    shared = np.isin(cu, ids[cnt >= 2])
+    if shared.any() and (~shared).any():
+        print("duration [ms], median: alone on its CU %.2f, sharing it %.2f" % (np.median(dur[~shared]) / 1e5, np.median(dur[shared]) / 1e5))
