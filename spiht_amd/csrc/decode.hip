@@ -615,7 +615,7 @@ template <bool META>
 __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const Geom &g, const Item &it, uint32_t seqno,
                                          uint32_t pre, uint32_t *nxt, uint32_t *ret, uint32_t *lip,
                                          uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
-                                         int32_t base_val, uint32_t lane, const Trace &tr) {
+                                         int32_t base_val, uint32_t lane, const Trace &tr, uint64_t *wpf = nullptr) {
     const uint32_t W = (uint32_t)g.w, H = (uint32_t)g.h;
     constexpr uint32_t IDXM = META ? ENT_IDX_META : ENT_IDX;
     // entry starts: owned bits that are not child bits of a fired type-A entry starting in this window
@@ -716,10 +716,16 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
     } else {
         Chain *pc = &sh.chain[(seqno - 1) % DEC_RING];
         uint32_t spins = 0;
+#ifdef DEC_PROF
+        const uint64_t tc0 = __builtin_amdgcn_s_memtime();
+#endif
         while (lds_load(&pc->seq) != seqno) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
         }
+#ifdef DEC_PROF
+        if (wpf) wpf[2] += __builtin_amdgcn_s_memtime() - tc0;
+#endif
         b_lsp = pc->lsp; b_lip = pc->lip; b_nxt = pc->nxt; b_ret = pc->ret;
     }
     {
@@ -769,7 +775,7 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
                                              const uint32_t *cur, uint32_t cur_len, uint32_t *nxt, uint32_t *ret,
                                              uint32_t *lsp_idx, int32_t *lsp_val, uint32_t nbits, int n,
                                              int32_t base_val, uint32_t wk, uint32_t lane, const Trace &tr,
-                                             const BitSrc &bs) {
+                                             const BitSrc &bs, uint64_t *wpf = nullptr) {
     // The window's queue entries are its one trip to memory, and beside an HBM-bound kernel that trip is what a window
     // costs (round 4: the sequencer waited for ring space a fifth of its time there): the entries of this worker's NEXT
     // window are requested, if the sequencer has published it already, before the current one is worked on.
@@ -779,6 +785,9 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
         bool got = false;
         uint32_t spins = 0;
         uint32_t *rdy = &sh.ring[myk % DEC_RING].ready;
+#ifdef DEC_PROF
+        const uint64_t tw0 = __builtin_amdgcn_s_memtime();
+#endif
         for (;;) {
             // relaxed workgroup-scope load = plain ds_read (a volatile read through the generic pointer is a flat load)
             if (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == myk + 1) {
@@ -792,6 +801,10 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
             if (++spins > SPIN_LIMIT) { sh.bad = 2; break; }
         }
         if (!got) break;
+#ifdef DEC_PROF
+        const uint64_t tw1 = __builtin_amdgcn_s_memtime();
+        if (wpf) { wpf[0] += tw1 - tw0; wpf[4] += 1; }
+#endif
         // the window's queue entries first (the only trip to memory of the window), then its bits from LDS
         uint32_t pre;
         if (have_next) pre = pre_next;
@@ -810,7 +823,17 @@ __device__ __forceinline__ void worker_phase(DecShared &sh, const DecArgs &a, co
             }
         }
         const Item it = slot_unpack(sh, bs, myk);
+#ifdef DEC_PROF
+        {   // what the compiler's own wait in front of the first use of `pre` costs: everything this wavefront has in flight
+            const uint64_t tv0 = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wpf) wpf[1] += __builtin_amdgcn_s_memtime() - tv0;
+        }
+        work_lis<META>(sh, a, g, it, myk, pre, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr, wpf);
+        if (wpf) wpf[3] += __builtin_amdgcn_s_memtime() - tw1;
+#else
         work_lis<META>(sh, a, g, it, myk, pre, nxt, ret, lip_app, lsp_idx, lsp_val, nbits, n, base_val, lane, tr);
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) lds_store(&sh.wdone[wk], myk / DEC_NWK + 1);
         myk += DEC_NWK;
@@ -981,6 +1004,7 @@ void k_decode(DecArgs a) {
         uint32_t phase = 0;
 #ifdef DEC_PROF
         uint64_t pf[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t wpf[5] = {0, 0, 0, 0, 0};  // worker 0: waiting for a window, for memory, for the chain; in windows in all; windows
         uint64_t pt = __builtin_amdgcn_s_memtime();
         const uint64_t pf_rt0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz, whatever the shader clock does
 #endif
@@ -1503,8 +1527,13 @@ void k_decode(DecArgs a) {
                 } else if (wave == 1) {
                     helper_phase(sh, bs, par, P >> 6, lane);
                 } else if (DEC_IS_WORKER(wave)) {
+#ifdef DEC_PROF
+                    worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, cur_len, nxt, ret, lsp_idx, lsp_val, nbits,
+                                       n, base_val, DEC_WK(wave), lane, tr, bs, wpf);
+#else
                     worker_phase<META>(sh, a, g, myk, par, nullptr, nullptr, lip, cur, cur_len, nxt, ret, lsp_idx, lsp_val, nbits,
                                        n, base_val, DEC_WK(wave), lane, tr, bs);
+#endif
                 }
                 PF_ADD(2);
                 __syncthreads();
@@ -1637,6 +1666,9 @@ void k_decode(DecArgs a) {
 #ifdef DEC_PROF
             PF_ADD(9);
             if (b == 0) for (int q = 0; q < 24; q++) a.err[16 + q] = (uint32_t)(q == 5 || q == 6 || q == 8 || q == 10 || q == 15 || q >= 17 ? pf[q] : (pf[q] >> 10));
+            }
+        if (b == 0 && threadIdx.x == 128) for (int q = 0; q < 5; q++) a.err[40 + q] = (uint32_t)(q == 4 ? wpf[q] : (wpf[q] >> 10));
+        if (threadIdx.x == 0) {
             if (b < 448) {  // where and when this workgroup ran (tools/prof_decode.py: spread over the CUs, stragglers)
                 uint32_t *r = a.err + 64 + 4 * b;
                 r[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]

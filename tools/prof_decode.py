@@ -73,6 +73,9 @@ for k, nm in enumerate(names):
         print("%-12s %d" % (nm, w[k]))
     else:
         print("%-12s %8.3f Mcycles (%.1f%%)" % (nm, w[k] * 1024 / 1e6, 100.0 * w[k] / max(tot, 1)))
+ww = list(words)[40:45]
+print("worker 0: %d windows; waiting for a window %.2f Mcycles, for memory (its own loads and stores in flight) %.2f, for the chain of list lengths %.2f, in windows in all %.2f (%.0f cycles a window)"
+      % (ww[4], ww[0] * 1024 / 1e6, ww[1] * 1024 / 1e6, ww[2] * 1024 / 1e6, ww[3] * 1024 / 1e6, ww[3] * 1024 / max(1, ww[4])))
 print("total %.3f Mcycles of the sequencer wavefront (s_memtime: shader clocks, 2.1-2.4 GHz => about %.2f ms)" % (tot * 1024 / 1e6, tot * 1024 / 2.4e9 * 1e3))
 
 if B > 1:
