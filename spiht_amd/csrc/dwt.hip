@@ -33,6 +33,12 @@
 #define DW_TW 64      // output cols per tile
 #endif
 #define DW_BLOCK 256
+#ifndef DWF_BLOCK
+#define DWF_BLOCK 192  // threads of a forward-transform workgroup (k_dwt_level); 132 of them hold an input column each.  Three
+                       // wavefronts instead of four: beside a list-decoder workgroup (192 of a SIMD's 512 registers) FIVE of these
+                       // workgroups fit a CU instead of four -- level 1 inside the pipelined step 6.3 instead of 6.55 ms, the step
+                       // 16.4 instead of 16.7; alone 4.2 instead of 4.05 ms (round 4)
+#endif
 
 // Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an L2).  Remap the linear block id so
 // that each XCD walks one contiguous range of tiles: neighbouring tiles (shared halo columns/rows on the read
@@ -134,7 +140,7 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
                                          uint32_t tbz) {
     constexpr int NC = 2 * DW_TW + F - 2;  // input columns needed by the tile
     constexpr int HC = (NC + 1) / 2;       // columns per parity plane
-    static_assert(NC <= DW_BLOCK, "one thread per input column");
+    static_assert(NC <= DWF_BLOCK, "one thread per input column");
     static_assert(NR == 2 * DW_TH + F - 2, "input rows needed");
     constexpr int RS = HC + 1;
     const int plane = (int)tbz;
@@ -200,10 +206,10 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
     int32_t *__restrict__ co = a.coeffs + (size_t)plane * a.enc_h * a.enc_w;
     double *__restrict__ llo = a.last ? nullptr : a.ll_out + (size_t)plane * a.out_h * a.out_w;
     uint32_t amax = 0;
-    constexpr int NU = (DW_TH * DW_TW + DW_BLOCK - 1) / DW_BLOCK;  // output positions per thread
+    constexpr int NU = (DW_TH * DW_TW + DWF_BLOCK - 1) / DWF_BLOCK;  // output positions per thread
 #pragma unroll
     for (int u = 0; u < NU; u++) {
-        const int p = tid + u * DW_BLOCK;
+        const int p = tid + u * DWF_BLOCK;
         const int o = p / DW_TW, wcol = p % DW_TW;
         const int oh = oh0 + o, ow = ow0 + wcol;
         if (o >= DW_TH || oh >= a.out_h || ow >= a.out_w) continue;
@@ -238,7 +244,7 @@ __device__ __forceinline__ void dwt_tile(const DwtKArgs &a, double (&s_lo)[2][PS
 }
 
 template <int F, uint32_t LOM, uint32_t HIM>
-__global__ __launch_bounds__(DW_BLOCK) void k_dwt_level(DwtKArgs a) {
+__global__ __launch_bounds__(DWF_BLOCK) void k_dwt_level(DwtKArgs a) {
     constexpr int NC = 2 * DW_TW + F - 2, NR = 2 * DW_TH + F - 2, HC = (NC + 1) / 2;
     // two column-parity planes; the padding makes the plane stride an odd multiple of 16 banks, so the even and odd
     // lanes of one ds_write_b64 lane group land on different banks
@@ -1520,7 +1526,7 @@ static int launch_dwt_FM(DwtKArgs a, int planes, hipStream_t st) {
     if (a.mode != 4) a.ov_h = min(a.out_h, (a.in_h + z + 2) / 2);
     if (a.mode != 4) a.ov_w = min(a.out_w, (a.in_w + z + 2) / 2);
     const uint32_t nt = (uint32_t)((a.out_w + DW_TW - 1) / DW_TW) * (uint32_t)((a.out_h + DW_TH - 1) / DW_TH) * (uint32_t)planes;
-    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DW_BLOCK), 0, st, a);
+    hipLaunchKernelGGL((k_dwt_level<F, LOM, HIM>), dim3(nt), dim3(DWF_BLOCK), 0, st, a);
     const int n_edge = (a.out_h - a.ov_h) * a.out_w + a.ov_h * (a.out_w - a.ov_w);
     if (n_edge > 0) hipLaunchKernelGGL(k_dwt_edge<F>, dim3((n_edge + 255) / 256, planes), dim3(256), 0, st, a);
     return (int)hipGetLastError();
