@@ -12,10 +12,12 @@
 //     bit; only a fired type-A entry (1 + 4..8 bits) shifts what follows.  Wavefront 0, the sequencer, hops from fired
 //     A to fired A with a hand-written scalar loop (find-first-set on `bits & type-mask`, token length by v_readlane)
 //     and publishes, per 64-bit window, the mask of fired entries through an LDS ring.  Wavefront 1, the helper, runs
-//     ahead of it and prepares each window's bits and per-position token lengths -- and, for the windows that meet a
-//     stretch of the queue that is all type A (most of them: profiles/r04_lis_type_runs.txt), the whole walk of the
-//     window for each of its nine possible entry points, so that the sequencer looks the window up instead of hopping
-//     through it.  The other wavefronts are workers:
+//     ahead of it in batches of 32 windows, one lane per window: each window's bits, its per-position token lengths
+//     (three bit planes, worked out with bitwise operations on the window's word) and the whole walk of the window
+//     under the hypothesis "all entries are type A" for each of its nine possible entry points -- where the entries
+//     a window meets ARE all type A (three windows of four at 1080p: profiles/r04_lis_type_runs.txt) the sequencer
+//     looks the window up instead of hopping through it, runs of such windows in a loop written in assembly.
+//     The other wavefronts are workers:
 //     they rebuild entry starts from the mask, lane = stream position, and produce next generation / retained list /
 //     LIP / LSP appends; the running list lengths pass from worker to worker through a small LDS chain.
 //   * refinement: bit t belongs to LSP entry t -- all wavefronts, no sequencing.
@@ -1391,7 +1393,8 @@ void k_decode(DecArgs a) {
                         // the type mask of the 64 entries ahead (four cross-lane reads, a funnel shift), the window's row of
                         // token lengths, the helper's progress -- and inside a stretch of the queue that is all type A none of
                         // that is needed: the entries ahead of type A are counted once (`ones`, from the chunk masks in TAv),
-                        // and while 64 or more remain, a window is its table row and its slot: about thirty instructions.
+                        // and while the next window's own entries (`cnt`, out of its table row) are no more than are left of
+                        // them, a window is its table row and its slot.
                         if (by_table) {
                             uint32_t ones = 0;
                             {
