@@ -62,3 +62,88 @@ def test_all_ones_and_all_zeros():
     check(M, M)
     check(M, 0)
     check(0, M)
+
+
+# ---- the all-type-A table of a window (decode.hip: helper_phase, second half) ----------------------------------------------
+def tok_len(e, q):
+    return 5 + ((e[0] >> q) & 1) + 2 * ((e[1] >> q) & 1) + 4 * ((e[2] >> q) & 1)
+
+
+def ctz(x):
+    return (x & -x).bit_length() - 1
+
+
+def table_by_merging(lo, hi):
+    """per entry point 0..8: (fired-entry positions, entries that start in the window, overhang), as the helper works them out:
+    the walk from entry point 0 in full, the others only until they fall in step with it"""
+    e = planes(lo, hi)
+    S0 = fm0 = 0
+    p = 0
+    while p < 64:
+        rem = lo >> p
+        if rem == 0:
+            S0 |= (M << p) & M
+            p = 64
+            break
+        q = p + ctz(rem)
+        S0 |= (((2 << (q - p)) - 1) << p) & M
+        fm0 |= 1 << q
+        p = q + tok_len(e, q)
+    exit0 = p - 64
+    rows = [(fm0, bin(S0).count("1"), exit0)]
+    for o in range(1, 9):
+        pp, cnt, ex, fmk = o, 0, 0, 0
+        while True:
+            if pp >= 64:
+                ex = pp - 64
+                break
+            z = ctz(((lo | S0) >> pp) | (1 << (63 - pp)))
+            cnt += z
+            pp += z
+            if (S0 >> pp) & 1:
+                cnt += bin(S0 >> pp).count("1")
+                fmk |= fm0 & ((M << pp) & M)
+                ex = exit0
+                break
+            if not (lo >> pp) & 1:
+                cnt += 1
+                ex = 0
+                pp = 64
+                break
+            fmk |= 1 << pp
+            cnt += 1
+            pp += tok_len(e, pp)
+        rows.append((fmk, cnt, ex))
+    return rows
+
+
+def table_by_walking(lo, hi, o):
+    """the same by the plain walk: every entry is type A, '0' takes one bit, '1' takes 5 + significant offspring"""
+    both = lo | (hi << 64)
+    p, cnt, fm = o, 0, 0
+    while p < 64:
+        cnt += 1
+        if (both >> p) & 1:
+            fm |= 1 << p
+            p += parse(both, p)
+        else:
+            p += 1
+    return fm, cnt, p - 64
+
+
+def test_table_rows_equal_the_plain_walk():
+    rnd = random.Random(5)
+    for density in (0.0, 0.02, 0.1, 0.3, 0.5, 0.8, 1.0):
+        for _ in range(300):
+            lo = sum((rnd.random() < density) << b for b in range(64))
+            hi = sum((rnd.random() < density) << b for b in range(64))
+            rows = table_by_merging(lo, hi)
+            for o in range(9):
+                assert rows[o] == table_by_walking(lo, hi, o), (hex(lo), hex(hi), o)
+    # fired entries right at the window's end, from every entry point
+    for tail in range(1, 10):
+        lo = (1 << 63) | (1 << (63 - tail))
+        for hi in (0, M, 0x155, 0x0F):
+            rows = table_by_merging(lo, hi)
+            for o in range(9):
+                assert rows[o] == table_by_walking(lo, hi, o), (hex(lo), hex(hi), o)
