@@ -24,6 +24,10 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), "libspiht_hip.so does not export %s" % s
     assert sorted(_lib.SYMBOLS) == declared
     assert L.spiht_abi_version() == 2
+    # the shipped library is not a diagnostic build (-DSPIHT_DIAG -DDEC_PROF: timers inside the list decoder's loops,
+    # tools/prof_decode.py): its entry points are not there
+    for s in ("spiht_debug_words", "spiht_debug_words_ext"):
+        assert not hasattr(L, s), "libspiht_hip.so is a diagnostic build (%s)" % s
 
 
 def test_package_surface_matches_reference_init():
