@@ -648,6 +648,7 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
     uint32_t sigm = 0, signm = 0, lipm = 0, cb = 0, cr = 0, ccol = 0;
     uint32_t cf = 0;  // META: filter of the offspring, in entry position (get_offspring_filter, :133-150)
     bool fired = false;
+    const bool far = it.Wb + 64u + 16u <= nbits;  // (wave-uniform) the window's tokens end before the stream does
     if (META && isE) tr_put(tr, mypos, isA ? 2u : 5u, n, e);  // action 2 (:735) / action 5 (:787)
     if (isE) {
         const uint32_t avail = nbits - mypos;  // >= 1: the sequencer never places an entry at or past nbits
@@ -671,6 +672,20 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
             }
             if (!isA) {
                 nQ = 4;
+            } else if (!META && far) {
+                // every token of this window lies wholly inside the stream: no look at the end of it per offspring
+                uint32_t o = 1;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t sg = (bits >> o) & 1u;
+                    sigm |= sg << q;
+                    signm |= (sg & (bits >> (o + 1))) << q;
+                    o += 1u + sg;
+                }
+                lipm = ~sigm & 15u;
+                nLSP = (uint32_t)__popc(sigm);
+                nLIP = 4u - nLSP;
+                nQ = (4 * ii + 3 < H && 4 * jj + 3 < W) ? 1u : 0u;  // :411-414
             } else {
                 bool stop = false;
                 uint32_t o = 1;
