@@ -769,6 +769,19 @@ __device__ __forceinline__ void work_lis(DecShared &sh, const DecArgs &a, const 
         } else {
             uint32_t ol = b_lip + mbcnt(mL0) + 2u * mbcnt(mL1) + 4u * mbcnt(mL2);
             uint32_t os = b_lsp + mbcnt(mS0) + 2u * mbcnt(mS1) + 4u * mbcnt(mS2);
+            if (!META && far) {
+                // every offspring goes to one of the two lists: one store of its index to the address picked, the value behind it
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t ci = cb + (q >> 1) * W + (q & 1);
+                    const bool sg = (sigm >> q) & 1u;
+                    uint32_t *dst = sg ? lsp_idx + os : lip + ol;
+                    *dst = ci;
+                    if (sg) lsp_val[os] = ((signm >> q) & 1u) ? base_val : -base_val;
+                    os += sg ? 1u : 0u;
+                    ol += sg ? 0u : 1u;
+                }
+            } else
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t ci = (cb + (q >> 1) * W + (q & 1)) | cf;
